@@ -1,0 +1,477 @@
+/*
+ * bssm_oracle.c -- CPU restatement of bayesSSM's particle-filter hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is imported, linked or
+ * executed by the product (bayesssm_amd/); only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker / baseline.
+ *
+ * PARITY STATUS: "parity unpinned" for log-likelihood values, seeded ancestor
+ * vectors and multinomial draws.  The reference (R + Rcpp) cannot be built or
+ * run in this environment (no R, no Rcpp headers) and its own test-suite holds
+ * no numeric golden vectors for the filter.  What IS pinned:
+ * the RNG-independent known-answer checks of tests/testthat/test-resampling.R
+ * (:2-28, :48-68, :190-202) which tests/test_oracle_golden.py re-expresses
+ * against this file, plus hand-derived small cases in tests/golden/.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout).  Arithmetic follows the reference operation by
+ * operation: plain left-to-right double sums where Rcpp sugar sums
+ * (src/resampling.cpp), long-double accumulation where R's sum()/colSums()
+ * accumulate (R/particle_filter_core.R:107,109,206,211,238), true division,
+ * same comparison directions, same clamps, same guards.
+ *
+ * Build:  gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (oracle/Makefile)
+ *
+ * Random numbers are INPUTS here.  The reference draws them from R's global
+ * generator inside user closures (rnorm) and inside the resamplers
+ * (R::runif / Rcpp::runif); this restatement takes the same draws as arrays so
+ * that a GPU run fed the identical draws can be compared value by value.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_ERR_NEGATIVE 1   /* "Weights must be non-negative"            */
+#define ORC_ERR_ZERO_SUM 2   /* "Sum of weights must be greater than 0"   */
+#define ORC_ERR_LENGTH 3     /* "Number of particles must match the length of weights" */
+#define ORC_ERR_ARG 4
+
+/* R's M_LN_SQRT_2PI (Rmath.h): log(sqrt(2*pi)) */
+#define ORC_LN_SQRT_2PI 0.918938533204672741780329736406
+
+enum { ORC_MODEL_LG = 0, ORC_MODEL_AR1SIN = 1 };
+enum { ORC_BPF = 0, ORC_APF = 1 };
+enum { ORC_SIS = 0, ORC_SISR = 1, ORC_SISAR = 2 };
+enum { ORC_STRATIFIED = 0, ORC_SYSTEMATIC = 1, ORC_MULTINOMIAL = 2 };
+
+/* ------------------------------------------------------------------------- */
+/* Resamplers: src/resampling.cpp                                             */
+/* ------------------------------------------------------------------------- */
+
+/* Shared front half of all three resamplers.
+ * src/resampling.cpp:6-10, :17-24, :44-51:
+ *   any(weights < 0) -> stop; total = sum(weights) (Rcpp sugar: double
+ *   accumulator, index order); total == 0 -> stop; prob = weights / total. */
+static int orc_validate_and_prob(int nw, const double *w, double *prob, double *total_out)
+{
+    for (int i = 0; i < nw; i++)
+        if (w[i] < 0) return ORC_ERR_NEGATIVE;
+    double total = 0.0;
+    for (int i = 0; i < nw; i++) total += w[i];
+    if (total == 0) return ORC_ERR_ZERO_SUM;
+    for (int i = 0; i < nw; i++) prob[i] = w[i] / total;
+    if (total_out) *total_out = total;
+    return ORC_OK;
+}
+
+/* Rcpp sugar cumsum: out[0] = x[0]; out[i] = out[i-1] + x[i]
+ * (src/resampling.cpp:25,52). */
+static void orc_cumsum(int nw, const double *x, double *out)
+{
+    if (nw <= 0) return;
+    out[0] = x[0];
+    for (int i = 1; i < nw; i++) out[i] = out[i - 1] + x[i];
+}
+
+/* Two-pointer walk, src/resampling.cpp:30-37 and :57-63:
+ *   while (j < size-1 && cum_sum[j] < u_scaled[i]) j++;  indices[i] = j+1 */
+static void orc_walk(int n, int nw, const double *cum, const double *u_scaled, int *out)
+{
+    int j = 0;
+    for (int i = 0; i < n; i++) {
+        while (j < nw - 1 && cum[j] < u_scaled[i]) j++;
+        out[i] = j + 1;
+    }
+}
+
+/* resample_systematic_cpp, src/resampling.cpp:43-66.
+ * U is the single R::runif(0,1) draw (:55).  u_scaled = (i + U) / n. */
+int orc_resample_systematic(int n, const double *w, int nw, double U, int *out,
+                            double *cum_out /* optional, length nw */)
+{
+    if (n < 0 || nw < 0) return ORC_ERR_ARG;
+    double *prob = (double *)malloc(sizeof(double) * (size_t)(nw > 0 ? nw : 1));
+    double *cum = (double *)malloc(sizeof(double) * (size_t)(nw > 0 ? nw : 1));
+    double *us = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int st = orc_validate_and_prob(nw, w, prob, NULL);
+    if (st == ORC_OK) {
+        orc_cumsum(nw, prob, cum);
+        for (int i = 0; i < n; i++) us[i] = ((double)i + U) / (double)n;
+        orc_walk(n, nw, cum, us, out);
+        if (cum_out) memcpy(cum_out, cum, sizeof(double) * (size_t)nw);
+    }
+    free(prob); free(cum); free(us);
+    return st;
+}
+
+/* resample_stratified_cpp, src/resampling.cpp:16-40.
+ * U[0..n) are the Rcpp::runif(n) draws in index order (:28). */
+int orc_resample_stratified(int n, const double *w, int nw, const double *U, int *out,
+                            double *cum_out)
+{
+    if (n < 0 || nw < 0) return ORC_ERR_ARG;
+    double *prob = (double *)malloc(sizeof(double) * (size_t)(nw > 0 ? nw : 1));
+    double *cum = (double *)malloc(sizeof(double) * (size_t)(nw > 0 ? nw : 1));
+    double *us = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int st = orc_validate_and_prob(nw, w, prob, NULL);
+    if (st == ORC_OK) {
+        orc_cumsum(nw, prob, cum);
+        for (int i = 0; i < n; i++) us[i] = ((double)i + U[i]) / (double)n;
+        orc_walk(n, nw, cum, us, out);
+        if (cum_out) memcpy(cum_out, cum, sizeof(double) * (size_t)nw);
+    }
+    free(prob); free(cum); free(us);
+    return st;
+}
+
+/* resample_multinomial_cpp, src/resampling.cpp:5-13.
+ * Validation and prob follow the reference.  The draw itself is
+ * Rcpp::sample(n, n, true, prob) -- third-party (Rcpp, unpinned; Walker alias
+ * or sorted inversion depending on the weights), NOT under /root/reference.
+ * This restatement uses plain inversion on the sequential cumulative sum:
+ * index = 1 + #{j < nw-1 : cum[j] < U_i}.  Same distribution, not the same
+ * stream: multinomial parity is DISTRIBUTIONAL ONLY ("parity unpinned"). */
+int orc_resample_multinomial(int n, const double *w, int nw, const double *U, int *out)
+{
+    if (n < 0 || nw < 0) return ORC_ERR_ARG;
+    double *prob = (double *)malloc(sizeof(double) * (size_t)(nw > 0 ? nw : 1));
+    double *cum = (double *)malloc(sizeof(double) * (size_t)(nw > 0 ? nw : 1));
+    int st = orc_validate_and_prob(nw, w, prob, NULL);
+    if (st == ORC_OK) {
+        orc_cumsum(nw, prob, cum);
+        for (int i = 0; i < n; i++) {
+            /* first j with !(cum[j] < U_i), clamped to nw-1 */
+            int lo = 0, hi = nw - 1;
+            while (lo < hi) {
+                int mid = lo + (hi - lo) / 2;
+                if (cum[mid] < U[i]) lo = mid + 1; else hi = mid;
+            }
+            out[i] = lo + 1;
+        }
+    }
+    free(prob); free(cum);
+    return st;
+}
+
+/* Sequential double sum and cumulative sum exposed for the exact-scan tests. */
+double orc_seq_sum(int n, const double *x)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += x[i];
+    return s;
+}
+void orc_seq_cumsum(int n, const double *x, double *out) { orc_cumsum(n, x, out); }
+
+/* ------------------------------------------------------------------------- */
+/* Built-in models (user closures of the reference, restated)                 */
+/* ------------------------------------------------------------------------- */
+/* theta layout, both models: theta[0]=phi, theta[1]=sigma_x, theta[2]=sigma_y.
+ *
+ * LG      tests/testthat/test-pmmh_tuning.R:163-173 generalised to (sigma_x,
+ *         sigma_y) as BASELINE C2/C3 use it:
+ *           init        rnorm(N, 0, 1)
+ *           transition  phi * particles + rnorm(N, 0, sigma_x)
+ *           loglik      dnorm(y, particles, sigma_y, log = TRUE)
+ * AR1SIN  README.md:137-146:
+ *           transition  phi * particles + sin(particles) + rnorm(N, 0, sigma_x)
+ *
+ * rnorm(n, mu, sd) = mu + sd * norm_rand()            (R nmath/rnorm.c)
+ * dnorm(x, mu, sd, log) = -(M_LN_SQRT_2PI + 0.5*z*z + log(sd)), z=|x-mu|/sd
+ *                                                      (R nmath/dnorm.c)     */
+
+static inline double orc_rnorm(double mu, double sd, double z) { return mu + sd * z; }
+
+static inline double orc_dnorm_log(double x, double mu, double sd, double log_sd)
+{
+    double z = (x - mu) / sd;
+    if (!isfinite(z)) return -INFINITY;
+    z = fabs(z);
+    return -(ORC_LN_SQRT_2PI + 0.5 * z * z + log_sd);
+}
+
+static void orc_transition(int model, const double *theta, int N, double *x, const double *z)
+{
+    const double phi = theta[0], sx = theta[1];
+    if (model == ORC_MODEL_LG) {
+        for (int i = 0; i < N; i++) x[i] = phi * x[i] + orc_rnorm(0.0, sx, z[i]);
+    } else {
+        for (int i = 0; i < N; i++) x[i] = phi * x[i] + sin(x[i]) + orc_rnorm(0.0, sx, z[i]);
+    }
+}
+
+static void orc_loglik(int model, const double *theta, int N, const double *x, double y, double *lw)
+{
+    (void)model;
+    const double sy = theta[2];
+    const double log_sy = log(sy);
+    for (int i = 0; i < N; i++) lw[i] = orc_dnorm_log(y, x[i], sy, log_sy);
+}
+
+/* Auxiliary log-likelihood for the APF on these two models: the reference's
+ * own APF test uses dnorm(y, mean = E[x_t | x_{t-1}], sd) evaluated at the
+ * CURRENT particles (tests/testthat/test-auxiliary_filter.R:24-27 pattern: forecast mean);
+ * R/particle_filter_core.R:142-147 calls it after the gap-loop transition. */
+static void orc_aux_loglik(int model, const double *theta, int N, const double *x, double y, double *lw)
+{
+    const double phi = theta[0], sy = theta[2];
+    const double log_sy = log(sy);
+    for (int i = 0; i < N; i++) {
+        double mean = (model == ORC_MODEL_LG) ? phi * x[i] : phi * x[i] + sin(x[i]);
+        lw[i] = orc_dnorm_log(y, mean, sy, log_sy);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* .particle_filter_core: R/particle_filter_core.R:19-267 (d = 1 models)      */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    /* inputs */
+    int model, algorithm, resample_algorithm, resample_fn;
+    int N, T;
+    double threshold;       /* < 0 => NULL => auto (R/particle_filter_core.R:44-50) */
+    const double *theta;    /* [3] */
+    const double *y;        /* [T] */
+    const int *obs_times;   /* [T] or NULL => 1..T (:71) */
+    const double *z_init;   /* [N] standard normals for init_fn */
+    const double *z_trans;  /* [n_trans_calls][N], consumed in call order */
+    const double *u_res;    /* systematic: [n_res_calls]; stratified/multinomial: [n_res_calls][N] */
+    /* outputs */
+    double *state_est;      /* [T+1] */
+    double *ess;            /* [T+1] */
+    double *loglike_history;/* [T]   */
+    double *loglike;        /* [1]   */
+    int *ancestors;         /* optional [n_res_calls][N], 1-based */
+    double *weights_hist;   /* optional [T+1][N] (weights_history, :244,:261) */
+    double *particles_hist; /* optional [T+1][N] (particles_history, :243,:258) */
+    int *n_trans_calls;     /* [1] out */
+    int *n_res_calls;       /* [1] out */
+    int *early_return_step; /* [1] out: 0 = ran to the end; i>0 = degenerate at obs i (:189-202) */
+    int *resampled;         /* optional [T]: 1 if the weight-triggered resample ran at obs i */
+} orc_pf_args;
+
+/* R sum(): long double accumulator (R summary.c rsum), rounded once. */
+static double orc_rsum(int n, const double *x)
+{
+    long double s = 0.0L;
+    for (int i = 0; i < n; i++) s += x[i];
+    return (double)s;
+}
+
+static int orc_resample_dispatch(int kind, int N, const double *w, const double *u, int *idx)
+{
+    if (kind == ORC_SYSTEMATIC) return orc_resample_systematic(N, w, N, u[0], idx, NULL);
+    if (kind == ORC_STRATIFIED) return orc_resample_stratified(N, w, N, u, idx, NULL);
+    return orc_resample_multinomial(N, w, N, u, idx);
+}
+
+int orc_pf_run(orc_pf_args *a)
+{
+    const int N = a->N, T = a->T;
+    if (N <= 0 || T < 0) return ORC_ERR_ARG;                 /* assert_count(num_particles, positive) :33 */
+    const double dN = (double)N;
+    double threshold = a->threshold;
+    if (threshold < 0) {                                       /* :44-50 */
+        threshold = (a->resample_algorithm == ORC_SIS) ? INFINITY
+                  : (a->resample_algorithm == ORC_SISR) ? dN : dN / 2;
+    }
+    const size_t ures_stride = (a->resample_fn == ORC_SYSTEMATIC) ? 1 : (size_t)N;
+
+    double *x = (double *)malloc(sizeof(double) * N);
+    double *xold = (double *)malloc(sizeof(double) * N);
+    double *lw = (double *)malloc(sizeof(double) * N);
+    double *auxlw = (double *)malloc(sizeof(double) * N);
+    double *w = (double *)malloc(sizeof(double) * N);
+    double *tmp = (double *)malloc(sizeof(double) * N);
+    int *idx = (int *)malloc(sizeof(int) * N);
+    int rc = ORC_OK, ktrans = 0, kres = 0;
+    *a->early_return_step = 0;
+
+    /* init_fn: rnorm(N, 0, 1) :76 */
+    for (int i = 0; i < N; i++) x[i] = orc_rnorm(0.0, 1.0, a->z_init[i]);
+
+    /* t = 0 :106-116.  weights = rep(1/N, N); ess[1] = 1/sum(w^2); state_est[1] = sum(x*w) */
+    for (int i = 0; i < N; i++) w[i] = 1.0 / dN;
+    for (int i = 0; i < N; i++) tmp[i] = w[i] * w[i];
+    a->ess[0] = 1.0 / orc_rsum(N, tmp);
+    for (int i = 0; i < N; i++) tmp[i] = x[i] * w[i];
+    a->state_est[0] = orc_rsum(N, tmp);
+    if (a->weights_hist) memcpy(a->weights_hist, w, sizeof(double) * N);
+    if (a->particles_hist) memcpy(a->particles_hist, x, sizeof(double) * N);
+
+    double loglike = 0.0;
+    int prev_t = 0;
+    for (int i = 1; i <= T; i++) {                            /* :123 */
+        const int ot = a->obs_times ? a->obs_times[i - 1] : i;
+        const int gap = ot - prev_t;                          /* :124 */
+        for (int step = 1; step <= gap; step++) {             /* :125-136 */
+            orc_transition(a->model, a->theta, N, x, a->z_trans + (size_t)ktrans * N);
+            ktrans++;
+        }
+        prev_t = ot;
+        const double yi = a->y[i - 1];
+
+        if (a->algorithm == ORC_APF) {                        /* :140-175 */
+            orc_aux_loglik(a->model, a->theta, N, x, yi, auxlw);
+            double max_aux = auxlw[0];
+            for (int k = 1; k < N; k++) if (auxlw[k] > max_aux) max_aux = auxlw[k];
+            for (int k = 0; k < N; k++) tmp[k] = exp(auxlw[k] - max_aux);   /* :153 */
+            double s = orc_rsum(N, tmp);
+            for (int k = 0; k < N; k++) tmp[k] = tmp[k] / s;                 /* :154 */
+            rc = orc_resample_dispatch(a->resample_fn, N, tmp,
+                                       a->u_res + (size_t)kres * ures_stride, idx);  /* :155 */
+            if (rc != ORC_OK) goto done;
+            if (a->ancestors) memcpy(a->ancestors + (size_t)kres * N, idx, sizeof(int) * N);
+            kres++;
+            memcpy(xold, x, sizeof(double) * N);
+            for (int k = 0; k < N; k++) x[k] = xold[idx[k] - 1];            /* :157 */
+            orc_transition(a->model, a->theta, N, x, a->z_trans + (size_t)ktrans * N); /* :159 */
+            ktrans++;
+            orc_loglik(a->model, a->theta, N, x, yi, lw);                    /* :169-174 */
+            for (int k = 0; k < N; k++) lw[k] = lw[k] - auxlw[idx[k] - 1];   /* :175 */
+        } else {
+            orc_loglik(a->model, a->theta, N, x, yi, lw);                    /* :177-182 */
+        }
+
+        int all_small = 1;                                    /* :189 all(log_weights < -1e8) */
+        for (int k = 0; k < N; k++) if (!(lw[k] < -1e8)) { all_small = 0; break; }
+        if (all_small) {
+            loglike = -INFINITY;
+            a->loglike_history[i - 1] = -INFINITY;
+            *a->early_return_step = i;
+            goto done;
+        }
+
+        double max_logw = lw[0];                              /* :204 */
+        for (int k = 1; k < N; k++) if (lw[k] > max_logw) max_logw = lw[k];
+        for (int k = 0; k < N; k++) tmp[k] = exp(lw[k] - max_logw);          /* :205 */
+        double weight_sum = orc_rsum(N, tmp);                 /* :206 */
+        for (int k = 0; k < N; k++) w[k] = tmp[k] / weight_sum;              /* :207 */
+        loglike = loglike + (max_logw + log(weight_sum) - log(dN));          /* :208 */
+        a->loglike_history[i - 1] = loglike;                  /* :209 cumulative */
+
+        for (int k = 0; k < N; k++) tmp[k] = w[k] * w[k];
+        double ess = 1.0 / orc_rsum(N, tmp);                  /* :211 */
+        a->ess[i] = ess;
+
+        int should = (a->resample_algorithm == ORC_SIS) ? 0
+                   : (a->resample_algorithm == ORC_SISR) ? 1 : (ess < threshold);   /* :214-218 */
+        if (a->resampled) a->resampled[i - 1] = should;
+        if (should) {                                         /* :220-224 */
+            rc = orc_resample_dispatch(a->resample_fn, N, w,
+                                       a->u_res + (size_t)kres * ures_stride, idx);
+            if (rc != ORC_OK) goto done;
+            if (a->ancestors) memcpy(a->ancestors + (size_t)kres * N, idx, sizeof(int) * N);
+            kres++;
+            memcpy(xold, x, sizeof(double) * N);
+            for (int k = 0; k < N; k++) x[k] = xold[idx[k] - 1];            /* R/resampling.R:40,60 */
+            for (int k = 0; k < N; k++) w[k] = 1.0 / dN;
+            a->ess[i] = dN;                                   /* :223 */
+        }
+        for (int k = 0; k < N; k++) tmp[k] = x[k] * w[k];
+        a->state_est[i] = orc_rsum(N, tmp);                   /* :238 */
+        if (a->weights_hist) memcpy(a->weights_hist + (size_t)i * N, w, sizeof(double) * N);
+        if (a->particles_hist) memcpy(a->particles_hist + (size_t)i * N, x, sizeof(double) * N);
+    }
+done:
+    *a->loglike = loglike;
+    *a->n_trans_calls = ktrans;
+    *a->n_res_calls = kres;
+    free(x); free(xold); free(lw); free(auxlw); free(w); free(tmp); free(idx);
+    return rc;
+}
+
+/* Number of transition_fn calls / resample calls the core will make at most
+ * (for sizing the injected-noise arrays). */
+void orc_pf_noise_shape(int algorithm, int T, const int *obs_times, int *max_trans, int *max_res)
+{
+    int last = (T > 0) ? (obs_times ? obs_times[T - 1] : T) : 0;
+    *max_trans = last + ((algorithm == ORC_APF) ? T : 0);
+    *max_res = T * ((algorithm == ORC_APF) ? 2 : 1);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Parameter transforms: R/utils.R:102-152                                    */
+/* ------------------------------------------------------------------------- */
+enum { ORC_TR_IDENTITY = 0, ORC_TR_LOG = 1, ORC_TR_LOGIT = 2 };
+
+void orc_transform_params(int p, const double *theta, const int *tr, double *out)
+{
+    for (int j = 0; j < p; j++)
+        out[j] = (tr[j] == ORC_TR_LOG) ? log(theta[j])
+               : (tr[j] == ORC_TR_LOGIT) ? log(theta[j] / (1 - theta[j])) : theta[j];
+}
+void orc_back_transform_params(int p, const double *z, const int *tr, double *out)
+{
+    for (int j = 0; j < p; j++)
+        out[j] = (tr[j] == ORC_TR_LOG) ? exp(z[j])
+               : (tr[j] == ORC_TR_LOGIT) ? 1 / (1 + exp(-z[j])) : z[j];
+}
+double orc_log_jacobian(int p, const double *theta, const int *tr)
+{
+    long double s = 0.0L;   /* R sum() */
+    for (int j = 0; j < p; j++)
+        s += (tr[j] == ORC_TR_LOG) ? log(theta[j])
+           : (tr[j] == ORC_TR_LOGIT) ? log(1 / (theta[j] * (1 - theta[j]))) : 0.0;
+    return (double)s;
+}
+
+/* ------------------------------------------------------------------------- */
+/* MCMC effective sample size: R/ESS.R:32-104 (host diagnostics)              */
+/* ------------------------------------------------------------------------- */
+/* mat is m x k column-major (R matrix).  Returns NaN for zero-variance chains
+ * (reference: warning + NA, :52-55). */
+double orc_mcmc_ess(int m, int k, const double *mat)
+{
+    if (m < 2 || k < 2) return NAN;
+    double *mean = (double *)malloc(sizeof(double) * k);
+    double *var = (double *)malloc(sizeof(double) * k);
+    for (int c = 0; c < k; c++) {
+        long double s = 0; for (int i = 0; i < m; i++) s += mat[(size_t)c * m + i];
+        mean[c] = (double)(s / m);
+        /* R mean(): second pass refinement */
+        long double t = 0; for (int i = 0; i < m; i++) t += (mat[(size_t)c * m + i] - mean[c]);
+        mean[c] = (double)(mean[c] + t / m);
+        long double v = 0; for (int i = 0; i < m; i++) { double d = mat[(size_t)c * m + i] - mean[c]; v += d * d; }
+        var[c] = (double)(v / (m - 1));
+    }
+    long double om = 0; for (int c = 0; c < k; c++) om += mean[c];
+    double overall = (double)(om / k);
+    long double bs = 0; for (int c = 0; c < k; c++) { double d = mean[c] - overall; bs += d * d; }
+    double b = (double)m / (k - 1) * (double)bs;                       /* :47 */
+    for (int c = 0; c < k; c++) if (var[c] == 0) { free(mean); free(var); return NAN; }
+    long double ws = 0; for (int c = 0; c < k; c++) ws += var[c];
+    double w = (double)(ws / k);                                        /* :56 */
+    double var_hat = ((double)(m - 1) / m) * w + (1.0 / m) * b;        /* :59 */
+    /* acf(x, lag.max = m-1): r_t = sum_{i} (x_i - xbar)(x_{i+t} - xbar) / sum (x_i - xbar)^2 */
+    double *rho = (double *)malloc(sizeof(double) * m);
+    double *acf = (double *)malloc(sizeof(double) * (size_t)m * k);
+    for (int c = 0; c < k; c++) {
+        const double *x = mat + (size_t)c * m;
+        long double d0 = 0; for (int i = 0; i < m; i++) { double d = x[i] - mean[c]; d0 += d * d; }
+        for (int t = 0; t < m; t++) {
+            long double s = 0;
+            for (int i = 0; i + t < m; i++) s += (x[i] - mean[c]) * (x[i + t] - mean[c]);
+            acf[(size_t)c * m + t] = (double)(s / d0);
+        }
+    }
+    for (int t = 0; t < m; t++) {                                      /* :69-72 */
+        long double s = 0; for (int c = 0; c < k; c++) s += var[c] * acf[(size_t)c * m + t];
+        double term = (1.0 / k) * (double)s;
+        rho[t] = 1 - (w - term) / var_hat;
+    }
+    int max_pairs = (m - 1) / 2;                                       /* :75 */
+    double sum_rho = 0, prev = 0;
+    for (int t = 1; t <= max_pairs; t++) {                            /* :77-98 */
+        double pr = rho[2 * t - 1] + rho[2 * t];
+        if (t >= 2 && pr > prev) pr = prev;
+        prev = pr;
+        if (pr < 0) break;
+        sum_rho += pr;
+    }
+    double tau = 1 + 2 * sum_rho;
+    free(mean); free(var); free(rho); free(acf);
+    return ((double)k * m) / tau;                                      /* :101 */
+}

@@ -1,0 +1,219 @@
+"""ctypes front-end of the CPU oracle (oracle/bssm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package `bayesssm_amd`.
+Parity status: see the header of bssm_oracle.c ("parity unpinned" for
+log-likelihood values / seeded ancestors / multinomial draws).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libbssm_oracle.so")
+
+OK, ERR_NEGATIVE, ERR_ZERO_SUM, ERR_LENGTH, ERR_ARG = 0, 1, 2, 3, 4
+ERROR_STRINGS = {
+    ERR_NEGATIVE: "Weights must be non-negative",              # src/resampling.cpp:6,18,45
+    ERR_ZERO_SUM: "Sum of weights must be greater than 0",     # src/resampling.cpp:8,22,49
+    ERR_LENGTH: "Number of particles must match the length of weights",  # R/resampling.R:17
+}
+MODEL = {"lg": 0, "ar1sin": 1}
+ALGORITHM = {"BPF": 0, "APF": 1}
+RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
+RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2}
+TRANSFORM = {"identity": 0, "log": 1, "logit": 2}
+
+
+def build(force=False):
+    """Compile the oracle with gcc (no-op when up to date)."""
+    src = os.path.join(_HERE, "bssm_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+class _PfArgs(C.Structure):
+    _fields_ = [
+        ("model", C.c_int), ("algorithm", C.c_int), ("resample_algorithm", C.c_int),
+        ("resample_fn", C.c_int), ("N", C.c_int), ("T", C.c_int),
+        ("threshold", C.c_double),
+        ("theta", C.c_void_p), ("y", C.c_void_p), ("obs_times", C.c_void_p),
+        ("z_init", C.c_void_p), ("z_trans", C.c_void_p), ("u_res", C.c_void_p),
+        ("state_est", C.c_void_p), ("ess", C.c_void_p), ("loglike_history", C.c_void_p),
+        ("loglike", C.c_void_p), ("ancestors", C.c_void_p), ("weights_hist", C.c_void_p),
+        ("particles_hist", C.c_void_p),
+        ("n_trans_calls", C.c_void_p), ("n_res_calls", C.c_void_p),
+        ("early_return_step", C.c_void_p), ("resampled", C.c_void_p),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_seq_sum.restype = C.c_double
+        _lib.orc_log_jacobian.restype = C.c_double
+        _lib.orc_mcmc_ess.restype = C.c_double
+    return _lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class ResampleError(ValueError):
+    def __init__(self, code):
+        super().__init__(ERROR_STRINGS.get(code, "oracle error %d" % code))
+        self.code = code
+
+
+def resample_systematic(n, weights, U, return_cum=False):
+    w = _d(weights)
+    out = np.empty(n, dtype=np.int32)
+    cum = np.empty(len(w)) if return_cum else None
+    st = lib().orc_resample_systematic(C.c_int(n), _p(w), C.c_int(len(w)), C.c_double(U), _p(out), _p(cum))
+    if st:
+        raise ResampleError(st)
+    return (out, cum) if return_cum else out
+
+
+def resample_stratified(n, weights, U, return_cum=False):
+    w, U = _d(weights), _d(U)
+    assert len(U) >= n
+    out = np.empty(n, dtype=np.int32)
+    cum = np.empty(len(w)) if return_cum else None
+    st = lib().orc_resample_stratified(C.c_int(n), _p(w), C.c_int(len(w)), _p(U), _p(out), _p(cum))
+    if st:
+        raise ResampleError(st)
+    return (out, cum) if return_cum else out
+
+
+def resample_multinomial(n, weights, U):
+    w, U = _d(weights), _d(U)
+    assert len(U) >= n
+    out = np.empty(n, dtype=np.int32)
+    st = lib().orc_resample_multinomial(C.c_int(n), _p(w), C.c_int(len(w)), _p(U), _p(out))
+    if st:
+        raise ResampleError(st)
+    return out
+
+
+def seq_sum(x):
+    x = _d(x)
+    return lib().orc_seq_sum(C.c_int(len(x)), _p(x))
+
+
+def seq_cumsum(x):
+    x = _d(x)
+    out = np.empty_like(x)
+    lib().orc_seq_cumsum(C.c_int(len(x)), _p(x), _p(out))
+    return out
+
+
+def noise_shape(algorithm, T, obs_times=None):
+    ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
+    mt, mr = C.c_int(0), C.c_int(0)
+    lib().orc_pf_noise_shape(C.c_int(ALGORITHM[algorithm]), C.c_int(T), _p(ot), C.byref(mt), C.byref(mr))
+    return mt.value, mr.value
+
+
+def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
+           resample_algorithm="SISAR", resample_fn="stratified", threshold=None,
+           obs_times=None, return_ancestors=False, return_particles=False):
+    """Restatement of .particle_filter_core (R/particle_filter_core.R:19-267)
+    with injected random draws.  Returns a dict shaped like the reference's
+    result list (state_est, ess, loglike, loglike_history, algorithm[,
+    resample_algorithm][, particles_history, weights_history])."""
+    y = _d(y)
+    T = len(y)
+    theta = _d(theta)
+    ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
+    z_init, z_trans, u_res = _d(z_init), _d(z_trans), _d(u_res)
+    max_trans, max_res = noise_shape(algorithm, T, obs_times)
+    assert z_init.size >= N
+    assert z_trans.size >= max_trans * N, (z_trans.size, max_trans, N)
+    need_u = max_res * (1 if resample_fn == "systematic" else N)
+    assert u_res.size >= need_u, (u_res.size, need_u)
+    state_est = np.zeros(T + 1)
+    ess = np.zeros(T + 1)
+    llh = np.zeros(T)
+    ll = np.zeros(1)
+    anc = np.zeros((max_res, N), dtype=np.int32) if return_ancestors else None
+    wh = np.full((T + 1, N), np.nan) if return_particles else None
+    ph = np.full((T + 1, N), np.nan) if return_particles else None
+    nt, nr, ers = (np.zeros(1, dtype=np.int32) for _ in range(3))
+    resampled = np.zeros(max(T, 1), dtype=np.int32)
+    a = _PfArgs(MODEL[model], ALGORITHM[algorithm], RESAMPLE_ALGORITHM[resample_algorithm],
+                RESAMPLE_FN[resample_fn], N, T,
+                -1.0 if threshold is None else float(threshold),
+                _p(theta), _p(y), _p(ot), _p(z_init), _p(z_trans), _p(u_res),
+                _p(state_est), _p(ess), _p(llh), _p(ll), _p(anc), _p(wh), _p(ph),
+                _p(nt), _p(nr), _p(ers), _p(resampled))
+    st = lib().orc_pf_run(C.byref(a))
+    if st:
+        raise ResampleError(st)
+    res = {"state_est": state_est, "ess": ess, "loglike": float(ll[0]),
+           "loglike_history": llh, "algorithm": algorithm,
+           "n_trans_calls": int(nt[0]), "n_res_calls": int(nr[0]),
+           "early_return_step": int(ers[0]), "resampled": resampled[:T]}
+    if ers[0] == 0:
+        res["resample_algorithm"] = resample_algorithm   # absent on early return (:192-196)
+    if return_ancestors:
+        res["ancestors"] = anc[: int(nr[0])]
+    if return_particles:
+        res["particles_history"] = ph
+        res["weights_history"] = wh
+    return res
+
+
+def transform_params(theta, tr):
+    theta = _d(theta)
+    t = np.ascontiguousarray([TRANSFORM[x] for x in tr], dtype=np.int32)
+    out = np.empty_like(theta)
+    lib().orc_transform_params(C.c_int(len(theta)), _p(theta), _p(t), _p(out))
+    return out
+
+
+def back_transform_params(z, tr):
+    z = _d(z)
+    t = np.ascontiguousarray([TRANSFORM[x] for x in tr], dtype=np.int32)
+    out = np.empty_like(z)
+    lib().orc_back_transform_params(C.c_int(len(z)), _p(z), _p(t), _p(out))
+    return out
+
+
+def log_jacobian(theta, tr):
+    theta = _d(theta)
+    t = np.ascontiguousarray([TRANSFORM[x] for x in tr], dtype=np.int32)
+    return lib().orc_log_jacobian(C.c_int(len(theta)), _p(theta), _p(t))
+
+
+def mcmc_ess(mat):
+    """R/ESS.R:32-104 on an m x k matrix (iterations x chains)."""
+    mat = np.asfortranarray(mat, dtype=np.float64)
+    m, k = mat.shape
+    return lib().orc_mcmc_ess(C.c_int(m), C.c_int(k), mat.ctypes.data_as(C.c_void_p))
+
+
+def kalman_loglik(y, phi, sigma_x, sigma_y, m0=0.0, p0=1.0):
+    """Exact log-likelihood of the linear-Gaussian model (independent analytic
+    check); not part of the reference."""
+    m, p, ll = m0, p0, 0.0
+    for yt in np.asarray(y, dtype=np.float64):
+        m, p = phi * m, phi * phi * p + sigma_x ** 2
+        s = p + sigma_y ** 2
+        ll += -0.5 * (np.log(2 * np.pi * s) + (yt - m) ** 2 / s)
+        k = p / s
+        m, p = m + k * (yt - m), (1 - k) * p
+    return ll
