@@ -1,0 +1,178 @@
+"""ctypes binding of libbayesssm_amd.so (the C ABI in include/bayesssm_amd.h).
+
+There is no CPU implementation behind this module: if the HIP library is not
+built, cannot be loaded, or no MI355X is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbayesssm_amd.so")
+
+OK, ERR_NEGATIVE, ERR_ZERO_SUM, ERR_LENGTH, ERR_ARG, ERR_HIP, ERR_CAPACITY = range(7)
+MODEL = {"lg": 0, "ar1sin": 1}
+ALGORITHM = {"BPF": 0, "APF": 1}
+RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
+RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2}
+TRANSFORM = {"identity": 0, "log": 1, "logit": 2}
+PRIOR = {"normal": 0, "exponential": 1, "uniform": 2, "flat": 3}
+
+
+class BssmError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+class PfConfig(C.Structure):
+    _fields_ = [
+        ("model", C.c_int), ("algorithm", C.c_int), ("resample_algorithm", C.c_int), ("resample_fn", C.c_int),
+        ("num_particles", C.c_longlong), ("T", C.c_int), ("threshold", C.c_double),
+        ("theta", C.c_void_p), ("n_theta", C.c_int), ("y", C.c_void_p), ("obs_times", C.c_void_p),
+        ("seed", C.c_ulonglong), ("stream", C.c_ulonglong),
+        ("z_init", C.c_void_p), ("z_trans", C.c_void_p), ("u_res", C.c_void_p),
+        ("return_particles", C.c_int), ("return_ancestors", C.c_int),
+    ]
+
+
+class PfResult(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in (
+        "state_est", "ess", "loglike_history", "loglike", "early_return_step", "n_res_calls", "resampled",
+        "ancestors", "particles_history", "weights_history", "device_ms")]
+
+
+class PmmhConfig(C.Structure):
+    _fields_ = [
+        ("pf", PfConfig), ("m", C.c_int), ("n_params", C.c_int),
+        ("init_theta", C.c_void_p), ("proposal_cov", C.c_void_p), ("transform", C.c_void_p),
+        ("prior_kind", C.c_void_p), ("prior_a", C.c_void_p), ("prior_b", C.c_void_p),
+        ("seed", C.c_ulonglong), ("chain_index", C.c_int), ("return_latent_state_est", C.c_int),
+    ]
+
+
+class PmmhResult(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("theta_chain", "loglike_chain", "state_est_chain", "accepted", "device_ms")]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library.  torch is imported first so that both share ONE HIP
+    runtime (same libamdhip64 SONAME) when torch.distributed is used for the
+    multi-GPU chain gather."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "bayesssm_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C bayesssm_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    if os.environ.get("BAYESSSM_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:   # torch is plumbing only; the library itself does not need it
+            pass
+    lib = C.CDLL(LIB_PATH)
+    lib.bssm_last_error.restype = C.c_char_p
+    lib.bssm_status_string.restype = C.c_char_p
+    lib.bssm_status_string.argtypes = [C.c_int]
+    lib.bssm_ctx_stream.restype = C.c_void_p
+    lib.bssm_ctx_stream.argtypes = [C.c_void_p]
+    lib.bssm_ctx_create.argtypes = [C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_void_p)]
+    lib.bssm_ctx_destroy.argtypes = [C.c_void_p]
+    lib.bssm_ctx_destroy.restype = None
+    lib.bssm_ctx_synchronize.argtypes = [C.c_void_p]
+    lib.bssm_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
+    lib.bssm_ctx_get_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bssm_resample_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bssm_resample_systematic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    lib.bssm_resample_stratified.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bssm_resample_multinomial.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bssm_resample_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bssm_resample_device_status.argtypes = [C.c_void_p]
+    lib.bssm_pf_run.argtypes = [C.c_void_p, C.POINTER(PfConfig), C.POINTER(PfResult)]
+    lib.bssm_pf_noise_shape.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bssm_dump_normals.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_int, C.c_longlong, C.c_void_p]
+    lib.bssm_dump_uniforms.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_longlong, C.c_void_p]
+    lib.bssm_pmmh_chain.argtypes = [C.c_void_p, C.POINTER(PmmhConfig), C.POINTER(PmmhResult)]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "bssm_ctx_create", "bssm_ctx_destroy", "bssm_last_error", "bssm_status_string", "bssm_device_count",
+    "bssm_ctx_synchronize", "bssm_ctx_stream", "bssm_resample_systematic", "bssm_resample_stratified",
+    "bssm_resample_multinomial", "bssm_resample_device", "bssm_resample_device_status", "bssm_resample_ex",
+    "bssm_pf_run", "bssm_pf_noise_shape", "bssm_dump_normals", "bssm_dump_uniforms",
+    "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_pmmh_chain",
+]
+
+
+def check(status):
+    if status != OK:
+        lib = load()
+        msg = lib.bssm_last_error().decode() or lib.bssm_status_string(status).decode()
+        raise BssmError(status, msg)
+
+
+class Context:
+    """One GPU + one HIP stream + the device workspace (bssm_ctx)."""
+
+    def __init__(self, device=0, max_particles=1 << 20, max_dim=1):
+        lib = load()
+        if lib.bssm_device_count() <= 0:
+            raise BssmError(ERR_HIP, "bayesssm_amd: no HIP device visible; this package has no CPU path")
+        h = C.c_void_p()
+        check(lib.bssm_ctx_create(device, max_particles, max_dim, C.byref(h)))
+        self._h = h
+        self.device = device
+        self.max_particles = max_particles
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self):
+        check(load().bssm_ctx_synchronize(self._h))
+
+    def set_profile(self, enable):
+        check(load().bssm_ctx_set_profile(self._h, 1 if enable else 0))
+
+    def get_profile(self):
+        n = 64
+        names = (C.c_char_p * n)()
+        ms = (C.c_double * n)()
+        cnt = (C.c_longlong * n)()
+        k = load().bssm_ctx_get_profile(self._h, n, names, ms, cnt)
+        return {names[i].decode(): {"ms": ms[i], "launches": cnt[i]} for i in range(k)}
+
+    def close(self):
+        if self._h:
+            load().bssm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(min_particles=1, device=None):
+    """Lazily created per-device context, grown when a larger filter is requested."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(load().bssm_device_count(), 1)
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx.max_particles < min_particles:
+        if ctx is not None:
+            ctx.close()
+        cap = max(1 << 16, 1 << (int(min_particles) - 1).bit_length())
+        ctx = Context(device, cap, 1)
+        _default_ctx[device] = ctx
+    return ctx

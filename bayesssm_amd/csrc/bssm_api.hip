@@ -1,0 +1,672 @@
+// bssm_api.hip -- C-ABI implementation (include/bayesssm_amd.h) over the kernels.
+//
+// Host-side sequencing of the reference's loops:
+//   bssm_pf_run      = .particle_filter_core's T-loop       R/particle_filter_core.R:123-246
+//   bssm_pmmh_chain  = chain_result's MH loop               R/pmmh.R:403-415,422-500
+// One context = one GPU + one stream; device memory is owned by the context.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <algorithm>
+#include "kernels.hip.h"
+#include "../../include/bayesssm_amd.h"
+
+using namespace bssm;
+
+static thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e__);                   \
+            return BSSM_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define ARGFAIL(msg) do { g_err = (msg); return BSSM_ERR_ARG; } while (0)
+
+struct ProfEntry { double ms = 0; long long launches = 0; };
+
+struct bssm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    long long cap = 0;          // particles
+    int max_dim = 1;
+    int maxB = 0;
+    // particle state
+    double *x0 = nullptr, *x1 = nullptr, *lw = nullptr, *w = nullptr, *auxlw = nullptr, *auxg = nullptr, *cum = nullptr;
+    // scan workspace
+    double *pm = nullptr, *ps = nullptr, *bsum = nullptr, *bsq = nullptr, *ain_w = nullptr, *ain_p = nullptr;
+    BlockRec* brec = nullptr;
+    uint64_t* cin = nullptr;
+    DevState* st = nullptr;
+    // growable buffers
+    std::map<std::string, std::pair<void*, size_t>> pool;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // profiling
+    bool profile = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    int last_device_status = 0;
+};
+
+static int pool_get(bssm_ctx* c, const char* name, size_t bytes, void** out)
+{
+    auto& e = c->pool[name];
+    if (e.second < bytes) {
+        if (e.first) HIPCHK(hipFree(e.first));
+        e.first = nullptr; e.second = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        HIPCHK(hipMalloc(&e.first, want));
+        e.second = want;
+    }
+    *out = e.first;
+    return BSSM_OK;
+}
+
+extern "C" const char* bssm_last_error(void) { return g_err.c_str(); }
+
+extern "C" const char* bssm_status_string(int status)
+{
+    switch (status) {
+        case BSSM_OK: return "ok";
+        case BSSM_ERR_NEGATIVE_WEIGHT: return "Weights must be non-negative";
+        case BSSM_ERR_ZERO_SUM: return "Sum of weights must be greater than 0";
+        case BSSM_ERR_LENGTH: return "Number of particles must match the length of weights";
+        case BSSM_ERR_ARG: return "invalid argument";
+        case BSSM_ERR_HIP: return "HIP runtime error";
+        case BSSM_ERR_CAPACITY: return "problem exceeds context capacity";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int bssm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim, bssm_ctx** out)
+{
+    if (!out) ARGFAIL("bssm_ctx_create: out is NULL");
+    *out = nullptr;
+    if (max_particles <= 0) ARGFAIL("bssm_ctx_create: max_particles must be positive");
+    if (max_dim < 1 || max_dim > 2) ARGFAIL("bssm_ctx_create: max_dim must be 1 or 2");
+    const long long B = (max_particles + EB - 1) / EB;
+    if (B > MAXB) { g_err = "bssm_ctx_create: max_particles exceeds 2^22 (scan workspace limit of this build)"; return BSSM_ERR_CAPACITY; }
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { g_err = "no HIP device visible: this library has no CPU path"; return BSSM_ERR_HIP; }
+    if (device < 0 || device >= ndev) ARGFAIL("bssm_ctx_create: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    bssm_ctx* c = new bssm_ctx();
+    c->device = device; c->cap = max_particles; c->max_dim = max_dim; c->maxB = (int)B;
+    const size_t npad = (size_t)B * EB;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); } };
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    A((void**)&c->x0, npad * 8 * max_dim); A((void**)&c->x1, npad * 8 * max_dim);
+    A((void**)&c->lw, npad * 8); A((void**)&c->w, npad * 8); A((void**)&c->auxlw, npad * 8); A((void**)&c->auxg, npad * 8);
+    A((void**)&c->cum, npad * 8);
+    A((void**)&c->pm, MAXB * 8); A((void**)&c->ps, MAXB * 8); A((void**)&c->bsum, MAXB * 8); A((void**)&c->bsq, MAXB * 8);
+    A((void**)&c->ain_w, MAXB * 8); A((void**)&c->ain_p, MAXB * 8);
+    A((void**)&c->brec, MAXB * sizeof(BlockRec)); A((void**)&c->cin, MAXB * 8);
+    A((void**)&c->st, sizeof(DevState));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<MODE_W>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXB * (int)sizeof(BlockRec));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<MODE_P>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXB * (int)sizeof(BlockRec));
+    if (e != hipSuccess) {
+        g_err = std::string("bssm_ctx_create: ") + hipGetErrorString(e);
+        bssm_ctx_destroy(c);
+        return BSSM_ERR_HIP;
+    }
+    *out = c;
+    return BSSM_OK;
+}
+
+extern "C" void bssm_ctx_destroy(bssm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->x0, c->x1, c->lw, c->w, c->auxlw, c->auxg, c->cum, c->pm, c->ps, c->bsum, c->bsq,
+                    c->ain_w, c->ain_p, c->brec, c->cin, c->st};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& kv : c->pool) if (kv.second.first) (void)hipFree(kv.second.first);
+    for (auto ev : c->ev_pool) (void)hipEventDestroy(ev);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int bssm_ctx_synchronize(bssm_ctx* c)
+{
+    if (!c) ARGFAIL("ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BSSM_OK;
+}
+
+extern "C" void* bssm_ctx_stream(bssm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int bssm_ctx_set_profile(bssm_ctx* c, int enable)
+{
+    if (!c) ARGFAIL("ctx is NULL");
+    c->profile = enable != 0;
+    c->prof.clear();
+    return BSSM_OK;
+}
+
+extern "C" int bssm_ctx_get_profile(bssm_ctx* c, int max_entries, const char** names, double* total_ms, long long* launches)
+{
+    if (!c) return 0;
+    int k = 0;
+    for (auto& kv : c->prof) {
+        if (k >= max_entries) break;
+        names[k] = kv.first.c_str(); total_ms[k] = kv.second.ms; launches[k] = kv.second.launches; k++;
+    }
+    return k;
+}
+
+// ---- launch helper: optional per-kernel-class HIP-event timing -------------------
+struct LaunchScope {
+    bssm_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    LaunchScope(bssm_ctx* c_, const char* n) : c(c_), name(n)
+    {
+        if (!c->profile) return;
+        auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~LaunchScope()
+    {
+        if (!c->profile) return;
+        (void)hipEventRecord(b, c->stream);
+        c->prof_pending.push_back({name, {a, b}});
+    }
+};
+static void prof_collect(bssm_ctx* c)
+{
+    for (auto& p : c->prof_pending) {
+        float ms = 0;
+        (void)hipEventSynchronize(p.second.second);
+        (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
+        auto& e = c->prof[p.first]; e.ms += ms; e.launches++;
+        c->ev_pool.push_back(p.second.first); c->ev_pool.push_back(p.second.second);
+    }
+    c->prof_pending.clear();
+}
+#define LAUNCH(c, name, kern, grid, block, shmem, ...)                                      \
+    do { LaunchScope ls__(c, name); hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, (c)->stream, __VA_ARGS__); } while (0)
+
+static PhiloxKey make_key(unsigned long long seed, unsigned long long stream)
+{
+    PhiloxKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32);
+    k.stream = (uint32_t)stream ^ (uint32_t)((stream >> 32) * 0x9E3779B9u);
+    return k;
+}
+
+// ---- the exact resampling pipeline on weights already in HBM ---------------------
+// resample_*_cpp: total = sum(w); prob = w/total; cum = cumsum(prob); walk.   src/resampling.cpp:16-66
+struct ResampleLaunch {
+    const double* d_w; long long nw; int n; int kind;
+    const double* d_u; long long u_stride; PhiloxKey key;
+    int* d_anc; long long anc_stride; double* d_cum;
+    const double* xsrc; double* xdst; int dim; long long xstride;
+    const double* auxsrc; double* auxdst; double* se_part;
+};
+
+static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
+{
+    const int B = (int)((r.nw + EB - 1) / EB);
+    const int lim = rec_window(r.nw);
+    const size_t shm = (size_t)B * sizeof(BlockRec);
+    LAUNCH(c, "k_local<W>", k_local<MODE_W>, B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->st);
+    LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NT, shm, r.d_w, r.nw, B, c->brec, c->cin, c->ain_w, c->ain_p, c->st);
+    LAUNCH(c, "k_local<P>", k_local<MODE_P>, B, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec, c->st);
+    LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NT, shm, r.d_w, r.nw, B, c->brec, c->cin, c->ain_w, c->ain_p, c->st);
+    ApplyArgs a;
+    a.w = r.d_w; a.nw = r.nw; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = r.n;
+    a.u_base = r.d_u; a.u_stride = r.u_stride; a.key = r.key;
+    a.anc_out = r.d_anc; a.anc_stride = r.anc_stride;
+    a.cum_out = (r.kind == BSSM_MULTINOMIAL) ? (r.d_cum ? r.d_cum : c->cum) : r.d_cum;
+    a.xsrc = r.xsrc; a.xdst = r.xdst; a.dim = r.dim; a.xstride = r.xstride;
+    a.auxsrc = r.auxsrc; a.auxdst = r.auxdst; a.se_part = r.se_part;
+    if (r.kind == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>", k_apply<1>, B, NT, 0, a, c->st);
+    else if (r.kind == BSSM_STRATIFIED) LAUNCH(c, "k_apply<stratified>", k_apply<0>, B, NT, 0, a, c->st);
+    else {
+        LAUNCH(c, "k_apply<cum>", k_apply<2>, B, NT, 0, a, c->st);
+        const int Bo = (int)(((long long)r.n + EB - 1) / EB);
+        LAUNCH(c, "k_multinomial", k_multinomial, Bo, NT, 0, a.cum_out, r.nw, r.n, a, c->st);
+    }
+}
+
+static int flags_to_status(uint32_t f)
+{
+    if (f & FLAG_NEGATIVE) return BSSM_ERR_NEGATIVE_WEIGHT;     // checked first, as the reference does
+    if (f & FLAG_NONFINITE) { g_err = "weights contain NaN/Inf"; return BSSM_ERR_ARG; }
+    if (f & FLAG_ZERO_SUM) return BSSM_ERR_ZERO_SUM;
+    return BSSM_OK;
+}
+
+static int resample_common_device(bssm_ctx* c, int kind, int n, const double* d_w, int nw, const double* d_u,
+                                  int* d_idx, double* d_cum)
+{
+    const int B = (nw + EB - 1) / EB;
+    LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
+    LAUNCH(c, "k_bsum", k_bsum, B, NT, 0, d_w, (long long)nw, c->bsum, c->st);
+    LAUNCH(c, "k_plan<resample>", k_plan<PLAN_RESAMPLE_ONLY>, 1, NT, 0, (const double*)nullptr, (const double*)nullptr, 0,
+           c->bsum, (const double*)nullptr, B, c->ain_w, c->st, (long long)nw, 0, 0, 0.0,
+           (double*)nullptr, (double*)nullptr, (int*)nullptr);
+    ResampleLaunch r;
+    r.d_w = d_w; r.nw = nw; r.n = n; r.kind = kind; r.d_u = d_u; r.u_stride = (kind == BSSM_SYSTEMATIC) ? 1 : n;
+    r.key = make_key(0, 0); r.d_anc = d_idx; r.anc_stride = 0; r.d_cum = d_cum;
+    r.xsrc = nullptr; r.xdst = nullptr; r.dim = 1; r.xstride = 0; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = nullptr;
+    launch_scan_and_apply(c, r);
+    return BSSM_OK;
+}
+
+extern "C" int bssm_resample_device(bssm_ctx* c, int kind, int n, const double* d_w, int nw, double U_scalar,
+                                    const double* d_U, int* d_idx, double* d_cum)
+{
+    if (!c) ARGFAIL("ctx is NULL");
+    if (n <= 0 || nw <= 0) ARGFAIL("bssm_resample_device: n and nw must be positive");
+    if (kind < 0 || kind > 2) ARGFAIL("bssm_resample_device: unknown resampler kind");
+    if ((long long)nw > c->cap || (long long)n > c->cap) { g_err = "bssm_resample_device: size exceeds context capacity"; return BSSM_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(c->device));
+    const double* du = d_U;
+    if (kind == BSSM_SYSTEMATIC && !d_U) {
+        void* p; int rc = pool_get(c, "u_scalar", 8, &p); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(p, &U_scalar, 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));   // U_scalar lives on the caller's stack
+        du = (const double*)p;
+    }
+    if (!du) ARGFAIL("bssm_resample_device: d_U is required for stratified/multinomial");
+    return resample_common_device(c, kind, n, d_w, nw, du, d_idx, d_cum);
+}
+
+extern "C" int bssm_resample_device_status(bssm_ctx* c)
+{
+    if (!c) ARGFAIL("ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    DevState h;
+    HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return flags_to_status(h.flags);
+}
+
+extern "C" int bssm_resample_ex(bssm_ctx* c, int kind, int n, const double* w, int nw, const double* U,
+                                int* idx_out, double* cum_out, long long* stats)
+{
+    if (!c) ARGFAIL("ctx is NULL");
+    if (!w || !idx_out || !U) ARGFAIL("bssm_resample: NULL pointer argument");
+    if (kind < 0 || kind > 2) ARGFAIL("bssm_resample: unknown resampler kind");
+    if (n <= 0 || nw <= 0) ARGFAIL("bssm_resample: n and nw must be positive");
+    if ((long long)nw > c->cap || (long long)n > c->cap) { g_err = "bssm_resample: size exceeds context capacity"; return BSSM_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(c->device));
+    void *dw, *du, *di, *dc = nullptr;
+    int rc;
+    const size_t nu = (kind == BSSM_SYSTEMATIC) ? 1 : (size_t)n;
+    if ((rc = pool_get(c, "rs_w", (size_t)nw * 8, &dw))) return rc;
+    if ((rc = pool_get(c, "rs_u", nu * 8, &du))) return rc;
+    if ((rc = pool_get(c, "rs_idx", (size_t)n * 4, &di))) return rc;
+    if (cum_out || kind == BSSM_MULTINOMIAL) { if ((rc = pool_get(c, "rs_cum", (size_t)nw * 8, &dc))) return rc; }
+    HIPCHK(hipMemcpyAsync(dw, w, (size_t)nw * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(du, U, nu * 8, hipMemcpyHostToDevice, c->stream));
+    rc = resample_common_device(c, kind, n, (const double*)dw, nw, (const double*)du, (int*)di, (double*)dc);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    DevState h;
+    HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (stats) { stats[0] = h.stat_hard_blocks; stats[1] = h.stat_serial_walks; stats[2] = h.stat_literal_terms; stats[3] = (nw + EB - 1) / EB; }
+    const int st = flags_to_status(h.flags);
+    if (st) { if (st != BSSM_ERR_ARG) g_err = bssm_status_string(st); return st; }
+    HIPCHK(hipMemcpy(idx_out, di, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (cum_out) HIPCHK(hipMemcpy(cum_out, dc, (size_t)nw * 8, hipMemcpyDeviceToHost));
+    return BSSM_OK;
+}
+
+extern "C" int bssm_resample_systematic(bssm_ctx* c, int n, const double* w, int nw, double U, int* out)
+{
+    return bssm_resample_ex(c, BSSM_SYSTEMATIC, n, w, nw, &U, out, nullptr, nullptr);
+}
+extern "C" int bssm_resample_stratified(bssm_ctx* c, int n, const double* w, int nw, const double* U, int* out)
+{
+    return bssm_resample_ex(c, BSSM_STRATIFIED, n, w, nw, U, out, nullptr, nullptr);
+}
+extern "C" int bssm_resample_multinomial(bssm_ctx* c, int n, const double* w, int nw, const double* U, int* out)
+{
+    return bssm_resample_ex(c, BSSM_MULTINOMIAL, n, w, nw, U, out, nullptr, nullptr);
+}
+
+// ---- generator dumps ---------------------------------------------------------------
+extern "C" int bssm_dump_normals(bssm_ctx* c, unsigned long long seed, unsigned long long stream, int purpose, int call,
+                                 long long n, double* out)
+{
+    if (!c || !out || n <= 0) ARGFAIL("bssm_dump_normals: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    void* d; int rc = pool_get(c, "dump", (size_t)n * 8, &d); if (rc) return rc;
+    const long long pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(k_dump_normals, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, c->stream,
+                       make_key(seed, stream), (uint32_t)purpose, (uint32_t)call, n, (double*)d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BSSM_OK;
+}
+extern "C" int bssm_dump_uniforms(bssm_ctx* c, unsigned long long seed, unsigned long long stream, int call, long long n, double* out)
+{
+    if (!c || !out || n <= 0) ARGFAIL("bssm_dump_uniforms: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    void* d; int rc = pool_get(c, "dump", (size_t)n * 8, &d); if (rc) return rc;
+    hipLaunchKernelGGL(k_dump_uniforms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       make_key(seed, stream), (uint32_t)call, n, (double*)d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BSSM_OK;
+}
+
+// ---- particle filter ---------------------------------------------------------------
+extern "C" int bssm_pf_noise_shape(int algorithm, int T, const int* obs_times, int* max_trans, int* max_res)
+{
+    if (T < 0 || !max_trans || !max_res) ARGFAIL("bssm_pf_noise_shape: bad argument");
+    const int last = (T > 0) ? (obs_times ? obs_times[T - 1] : T) : 0;
+    *max_trans = last + ((algorithm == BSSM_APF) ? T : 0);
+    *max_res = T * ((algorithm == BSSM_APF) ? 2 : 1);
+    return BSSM_OK;
+}
+
+template <int MODEL>
+static void launch_step(bssm_ctx* c, bool trans, int weight, bool subaux, double* x, long long N, int B,
+                        const ModelPar& par, double y, const NoiseSrc& ns)
+{
+#define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->st
+    if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step<trans+weight>", (k_step<MODEL, true, 1, false>), B, NT, 0, STEP_ARGS);
+    else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step<trans+weight-aux>", (k_step<MODEL, true, 1, true>), B, NT, 0, STEP_ARGS);
+    else if (trans && weight == 0) LAUNCH(c, "k_step<trans>", (k_step<MODEL, true, 0, false>), B, NT, 0, STEP_ARGS);
+    else if (!trans && weight == 2) {
+        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NT, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->st);
+    }
+#undef STEP_ARGS
+}
+
+static void launch_step_model(bssm_ctx* c, int model, bool trans, int weight, bool subaux, double* x, long long N, int B,
+                              const ModelPar& par, double y, const NoiseSrc& ns)
+{
+    if (model == BSSM_MODEL_LG) launch_step<0>(c, trans, weight, subaux, x, N, B, par, y, ns);
+    else launch_step<1>(c, trans, weight, subaux, x, N, B, par, y, ns);
+}
+
+extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* res)
+{
+    if (!c || !cfg || !res) ARGFAIL("bssm_pf_run: NULL argument");
+    const long long N = cfg->num_particles;
+    const int T = cfg->T;
+    if (N <= 0) ARGFAIL("num_particles must be a positive count");                    // assert_count(..., positive = TRUE) :33
+    if (T < 0) ARGFAIL("bssm_pf_run: T must be >= 0");
+    if (N > c->cap) { g_err = "bssm_pf_run: num_particles exceeds context capacity"; return BSSM_ERR_CAPACITY; }
+    if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN) ARGFAIL("bssm_pf_run: unknown model");
+    if (cfg->algorithm != BSSM_BPF && cfg->algorithm != BSSM_APF) ARGFAIL("bssm_pf_run: unknown algorithm");
+    if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run: unknown resample_algorithm");
+    if (cfg->resample_fn < 0 || cfg->resample_fn > 2) ARGFAIL("bssm_pf_run: unknown resample_fn");
+    if (!cfg->theta || cfg->n_theta < 3) ARGFAIL("bssm_pf_run: theta must hold (phi, sigma_x, sigma_y)");
+    if (T > 0 && !cfg->y) ARGFAIL("bssm_pf_run: y is NULL");
+    if (!res->state_est || !res->ess || !res->loglike || (T > 0 && !res->loglike_history)) ARGFAIL("bssm_pf_run: result buffers missing");
+    for (int i = 0; i < T; i++) if (!isfinite(cfg->y[i])) ARGFAIL("Assertion on 'y' failed: Contains missing values");  // assert_numeric(y, any.missing = FALSE) :69
+    if (cfg->obs_times) {                                                                   // assert_integerish(lower = 1, sorted = TRUE) :73
+        int prev = 1;
+        for (int i = 0; i < T; i++) { if (cfg->obs_times[i] < prev) ARGFAIL("Assertion on 'obs_times' failed: Must be sorted and >= 1"); prev = cfg->obs_times[i]; }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const int dim = 1;
+    const int B = (int)((N + EB - 1) / EB);
+    const bool apf = cfg->algorithm == BSSM_APF;
+    const double dN = (double)N;
+    double threshold = cfg->threshold;
+    if (threshold < 0) threshold = (cfg->resample_algorithm == BSSM_SIS) ? INFINITY : (cfg->resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
+    int max_trans = 0, max_res = 0;
+    bssm_pf_noise_shape(cfg->algorithm, T, cfg->obs_times, &max_trans, &max_res);
+    const long long u_stride = (cfg->resample_fn == BSSM_SYSTEMATIC) ? 1 : N;
+
+    // per-run device outputs
+    void *d_ess, *d_llh, *d_se, *d_separt, *d_resampled, *d_anc = nullptr, *d_ph = nullptr, *d_wh = nullptr;
+    void *d_zi = nullptr, *d_zt = nullptr, *d_ur = nullptr;
+    int rc;
+    if ((rc = pool_get(c, "ess", (size_t)(T + 1) * 8, &d_ess))) return rc;
+    if ((rc = pool_get(c, "llh", (size_t)(T + 1) * 8, &d_llh))) return rc;
+    if ((rc = pool_get(c, "se", (size_t)(T + 1) * dim * 8, &d_se))) return rc;
+    if ((rc = pool_get(c, "separt", (size_t)(T + 1) * B * dim * 8, &d_separt))) return rc;
+    if ((rc = pool_get(c, "resampled", (size_t)(T + 1) * 4, &d_resampled))) return rc;
+    if (cfg->return_ancestors) { if (!res->ancestors) ARGFAIL("bssm_pf_run: ancestors buffer missing"); if ((rc = pool_get(c, "anc", (size_t)std::max(max_res, 1) * N * 4, &d_anc))) return rc; }
+    if (cfg->return_particles) {
+        if (!res->particles_history || !res->weights_history) ARGFAIL("bssm_pf_run: history buffers missing");
+        if ((rc = pool_get(c, "ph", (size_t)(T + 1) * N * dim * 8, &d_ph))) return rc;
+        if ((rc = pool_get(c, "wh", (size_t)(T + 1) * N * 8, &d_wh))) return rc;
+    }
+    if (cfg->z_init) { if ((rc = pool_get(c, "zi", (size_t)N * 8, &d_zi))) return rc; HIPCHK(hipMemcpyAsync(d_zi, cfg->z_init, (size_t)N * 8, hipMemcpyHostToDevice, c->stream)); }
+    if (cfg->z_trans && max_trans > 0) { if ((rc = pool_get(c, "zt", (size_t)max_trans * N * 8, &d_zt))) return rc; HIPCHK(hipMemcpyAsync(d_zt, cfg->z_trans, (size_t)max_trans * N * 8, hipMemcpyHostToDevice, c->stream)); }
+    if (cfg->u_res && max_res > 0) { if ((rc = pool_get(c, "ur", (size_t)max_res * u_stride * 8, &d_ur))) return rc; HIPCHK(hipMemcpyAsync(d_ur, cfg->u_res, (size_t)max_res * u_stride * 8, hipMemcpyHostToDevice, c->stream)); }
+    HIPCHK(hipMemsetAsync(d_separt, 0, (size_t)(T + 1) * B * dim * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_ess, 0, (size_t)(T + 1) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_llh, 0, (size_t)(T + 1) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_resampled, 0, (size_t)(T + 1) * 4, c->stream));
+    if (d_anc) HIPCHK(hipMemsetAsync(d_anc, 0, (size_t)std::max(max_res, 1) * N * 4, c->stream));
+
+    ModelPar par; par.phi = cfg->theta[0]; par.sx = cfg->theta[1]; par.sy = cfg->theta[2]; par.log_sy = log(cfg->theta[2]);
+    const PhiloxKey key = make_key(cfg->seed, cfg->stream);
+    double* X0 = c->x0; double* X1 = c->x1;
+    double* separt = (double*)d_separt;
+
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
+    {   // t = 0  (:76-116)
+        NoiseSrc ns; ns.arr = (const double*)d_zi; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
+        LAUNCH(c, "k_init", k_init, B, NT, 0, X0, N, ns, separt);
+        if (cfg->return_particles) {
+            // weights = rep(1/N, N): do_resample is 0 after reset, so seed row 0 from a constant fill
+            std::vector<double> w0((size_t)N, 1.0 / dN);
+            HIPCHK(hipMemcpyAsync(d_wh, w0.data(), (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpyAsync(d_ph, X0, (size_t)N * dim * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    int ktrans = 0, prev_t = 0;
+    for (int i = 1; i <= T; i++) {                                                        // :123
+        const int ot = cfg->obs_times ? cfg->obs_times[i - 1] : i;
+        const int gap = ot - prev_t;                                                      // :124
+        prev_t = ot;
+        const double yi = cfg->y[i - 1];
+        auto noise = [&](int k) { NoiseSrc ns; ns.arr = d_zt ? (const double*)d_zt + (size_t)k * N : nullptr; ns.key = key; ns.purpose = DRAW_TRANS; ns.call = (uint32_t)k; return ns; };
+        ResampleLaunch r;
+        r.d_w = c->w; r.nw = N; r.n = (int)N; r.kind = cfg->resample_fn; r.d_u = (const double*)d_ur; r.u_stride = u_stride; r.key = key;
+        r.d_anc = (int*)d_anc; r.anc_stride = N; r.d_cum = nullptr; r.dim = dim; r.xstride = N;
+        // gap transitions; the last one is fused with the weight evaluation unless APF  (:125-136)
+        for (int step = 1; step <= gap; step++) {
+            const bool fuse_w = (!apf && step == gap);
+            launch_step_model(c, cfg->model, true, fuse_w ? 1 : 0, false, X0, N, B, par, yi, noise(ktrans));
+            ktrans++;
+        }
+        if (apf) {                                                                        // :140-175
+            launch_step_model(c, cfg->model, false, 2, false, X0, N, B, par, yi, noise(0));
+            LAUNCH(c, "k_normalize", k_normalize, B, NT, 0, c->auxlw, c->w, N, c->pm, c->ps, B, c->bsum, c->bsq, 0, c->st);
+            LAUNCH(c, "k_plan<aux>", k_plan<PLAN_AUX>, 1, NT, 0, c->pm, c->ps, B, c->bsum, c->bsq, B, c->ain_w, c->st, N, i,
+                   cfg->resample_algorithm, threshold, (double*)d_ess, (double*)d_llh, (int*)nullptr);
+            r.xsrc = X0; r.xdst = X1; r.auxsrc = c->auxlw; r.auxdst = c->auxg; r.se_part = nullptr;
+            launch_scan_and_apply(c, r);
+            std::swap(X0, X1);
+            launch_step_model(c, cfg->model, true, 1, true, X0, N, B, par, yi, noise(ktrans));   // :159-175
+            ktrans++;
+        } else if (gap <= 0) {
+            // obs_times repeats a time: no transition, weights on the current particles
+            NoiseSrc ns = noise(0);
+            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NT, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
+            else LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NT, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
+        }
+        LAUNCH(c, "k_normalize", k_normalize, B, NT, 0, c->lw, c->w, N, c->pm, c->ps, B, c->bsum, c->bsq, 1, c->st);       // :204-207
+        LAUNCH(c, "k_plan<pf>", k_plan<PLAN_PF>, 1, NT, 0, c->pm, c->ps, B, c->bsum, c->bsq, B, c->ain_w, c->st, N, i,
+               cfg->resample_algorithm, threshold, (double*)d_ess, (double*)d_llh, (int*)d_resampled);                     // :208-218
+        double* se_row = separt + (size_t)i * B * dim;
+        if (cfg->resample_algorithm != BSSM_SIS) {                                                                          // :220-224
+            r.xsrc = X0; r.xdst = X1; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = se_row;
+            launch_scan_and_apply(c, r);
+        }
+        if (cfg->resample_algorithm != BSSM_SISR)
+            LAUNCH(c, "k_carry", k_carry, B, NT, 0, X0, X1, c->w, N, dim, se_row, c->st);
+        std::swap(X0, X1);
+        if (cfg->return_particles) {
+            LAUNCH(c, "k_record_history", k_record_history, (unsigned)((N + 255) / 256), 256, 0, X0, c->w, N, dim,
+                   (double*)d_ph + (size_t)i * N * dim, (double*)d_wh + (size_t)i * N, c->st);
+        }
+    }
+    LAUNCH(c, "k_reduce_state_est", k_reduce_state_est, T + 1, NT, 0, separt, B, dim, (double*)d_se);
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipGetLastError());
+    DevState h;
+    HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(res->state_est, d_se, (size_t)(T + 1) * dim * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(res->ess, d_ess, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (T > 0) HIPCHK(hipMemcpyAsync(res->loglike_history, d_llh, (size_t)T * 8, hipMemcpyDeviceToHost, c->stream));
+    if (res->resampled && T > 0) HIPCHK(hipMemcpyAsync(res->resampled, d_resampled, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (res->device_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *res->device_ms = ms; }
+    // ess[1] = 1 / sum(rep(1/N, N)^2)   (:106-107)
+    res->ess[0] = 1.0 / (dN * ((1.0 / dN) * (1.0 / dN)));
+    *res->loglike = h.loglike;
+    if (res->early_return_step) *res->early_return_step = h.dead;
+    if (res->n_res_calls) *res->n_res_calls = h.res_calls;
+    if (h.dead) {   // the reference returns at once: later rows keep their initial values (:90-97)
+        for (int i = h.dead; i <= T; i++) { res->ess[i] = 0.0; for (int d = 0; d < dim; d++) res->state_est[(size_t)i * dim + d] = 0.0; }
+        for (int i = h.dead; i < T; i++) res->loglike_history[i] = 0.0;
+    }
+    if (h.flags) {
+        const int st = flags_to_status(h.flags);
+        if (st != BSSM_ERR_ARG) g_err = bssm_status_string(st);
+        return st;
+    }
+    if (cfg->return_ancestors && h.res_calls > 0) HIPCHK(hipMemcpy(res->ancestors, d_anc, (size_t)h.res_calls * N * 4, hipMemcpyDeviceToHost));
+    if (cfg->return_particles) {
+        const int rows = h.dead ? h.dead : T + 1;
+        HIPCHK(hipMemcpy(res->particles_history, d_ph, (size_t)rows * N * dim * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(res->weights_history, d_wh, (size_t)rows * N * 8, hipMemcpyDeviceToHost));
+    }
+    return BSSM_OK;
+}
+
+// ---- PMMH: one chain --------------------------------------------------------------------
+// Chain-level draws (proposal normals, acceptance uniform) come from the same
+// counter-based generator, keyed by the chain seed: results do not depend on
+// which GPU runs the chain.
+static double host_normal(const PhiloxKey& key, uint32_t iter, uint32_t j)
+{
+    u32x4 cn; cn.x = j; cn.y = iter; cn.z = DRAW_PROPOSAL; cn.w = key.stream;
+    const u32x4 r = philox4x32_10(cn, key.k0, key.k1);
+    return qnorm_as241(u01_from_bits(r.x, r.y));
+}
+static double host_uniform(const PhiloxKey& key, uint32_t iter)
+{
+    u32x4 cn; cn.x = 0; cn.y = iter; cn.z = DRAW_ACCEPT; cn.w = key.stream;
+    const u32x4 r = philox4x32_10(cn, key.k0, key.k1);
+    return u01_from_bits(r.x, r.y);
+}
+static double log_prior(int kind, double a, double b, double x)
+{
+    switch (kind) {
+        case BSSM_PRIOR_NORMAL: { const double z = (x - a) / b; return -(BSSM_LN_SQRT_2PI + 0.5 * z * z + log(b)); }   // dnorm(log=TRUE)
+        case BSSM_PRIOR_EXP: return (x < 0) ? -INFINITY : (log(a) - a * x);                                         // dexp(rate, log=TRUE)
+        case BSSM_PRIOR_UNIFORM: return (x >= a && x <= b) ? -log(b - a) : -INFINITY;                               // dunif(log=TRUE)
+        default: return 0.0;
+    }
+}
+static double tr_fwd(int tr, double x) { return tr == BSSM_TR_LOG ? log(x) : tr == BSSM_TR_LOGIT ? log(x / (1 - x)) : x; }          // R/utils.R:102-112
+static double tr_back(int tr, double z) { return tr == BSSM_TR_LOG ? exp(z) : tr == BSSM_TR_LOGIT ? 1 / (1 + exp(-z)) : z; }        // R/utils.R:122-132
+static double tr_logjac(int tr, double x) { return tr == BSSM_TR_LOG ? log(x) : tr == BSSM_TR_LOGIT ? log(1 / (x * (1 - x))) : 0.0; }  // R/utils.R:142-152
+
+extern "C" int bssm_pmmh_chain(bssm_ctx* c, const bssm_pmmh_config* cfg, bssm_pmmh_result* res)
+{
+    if (!c || !cfg || !res) ARGFAIL("bssm_pmmh_chain: NULL argument");
+    const int p = cfg->n_params, m = cfg->m, T = cfg->pf.T;
+    if (p < 1 || p > 16) ARGFAIL("bssm_pmmh_chain: n_params out of range");
+    if (m < 1) ARGFAIL("Assertion on 'm' failed: Must be >= 1");                         // assert_int(m, lower = 1) R/pmmh.R:264
+    if (!cfg->init_theta || !cfg->proposal_cov || !cfg->transform || !cfg->prior_kind || !cfg->prior_a || !cfg->prior_b)
+        ARGFAIL("bssm_pmmh_chain: NULL configuration array");
+    if (!res->theta_chain) ARGFAIL("bssm_pmmh_chain: theta_chain buffer missing");
+    // proposal covariance on the transformed scale: J Sigma J, J = diag(dz/dtheta at init_theta)   R/pmmh.R:378-389
+    std::vector<double> scale(p), cov(p * p), L(p * p, 0.0);
+    for (int j = 0; j < p; j++) {
+        const double th = cfg->init_theta[j];
+        scale[j] = cfg->transform[j] == BSSM_TR_LOG ? 1 / th : cfg->transform[j] == BSSM_TR_LOGIT ? 1 / (th * (1 - th)) : 1.0;
+    }
+    for (int a = 0; a < p; a++) for (int b = 0; b < p; b++) cov[a * p + b] = scale[a] * cfg->proposal_cov[a * p + b] * scale[b];
+    // mvrnorm(1, mu, Sigma): Cholesky factor here (MASS uses an eigen-decomposition; same law)
+    for (int a = 0; a < p; a++) {
+        for (int b = 0; b <= a; b++) {
+            double s = cov[a * p + b];
+            for (int k = 0; k < b; k++) s -= L[a * p + k] * L[b * p + k];
+            if (a == b) { if (!(s > 0)) ARGFAIL("'Sigma' is not positive definite"); L[a * p + a] = sqrt(s); }
+            else L[a * p + b] = s / L[b * p + b];
+        }
+    }
+    const PhiloxKey ckey = make_key(cfg->seed, 0x50000000ull + (unsigned long long)cfg->chain_index);
+    std::vector<double> cur(cfg->init_theta, cfg->init_theta + p), prop(p), z(p), ztr(p), lp_prop(p);
+    std::vector<double> se_cur((size_t)T + 1), se_prop((size_t)T + 1), ess((size_t)T + 1), llh((size_t)std::max(T, 1));
+    double ll = 0, ms = 0, ms_total = 0;
+    int ers = 0, nres = 0;
+    bssm_pf_config pf = cfg->pf;
+    pf.n_theta = p; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
+    pf.seed = cfg->seed;
+    bssm_pf_result pr; memset(&pr, 0, sizeof(pr));
+    pr.ess = ess.data(); pr.loglike_history = llh.data(); pr.loglike = &ll; pr.early_return_step = &ers; pr.n_res_calls = &nres; pr.device_ms = &ms;
+    auto run_pf = [&](const std::vector<double>& th, std::vector<double>& se, unsigned iter) -> int {
+        pf.theta = th.data(); pr.state_est = se.data();
+        pf.stream = ((unsigned long long)cfg->chain_index << 32) | iter;
+        const int rc = bssm_pf_run(c, &pf, &pr);
+        ms_total += ms;
+        return rc;
+    };
+    int rc = run_pf(cur, se_cur, 0);                                                     // R/pmmh.R:403-417
+    if (rc) return rc;
+    double cur_ll = ll;
+    int accepted = 0;
+    auto store = [&](int i) {
+        for (int j = 0; j < p; j++) res->theta_chain[(size_t)i * p + j] = cur[j];
+        if (res->loglike_chain) res->loglike_chain[i] = cur_ll;
+        if (res->state_est_chain) memcpy(res->state_est_chain + (size_t)i * (T + 1), se_cur.data(), sizeof(double) * (T + 1));
+    };
+    store(0);
+    for (int i = 1; i < m; i++) {                                                        // for (i in 2:m)  R/pmmh.R:422
+        for (int j = 0; j < p; j++) { ztr[j] = tr_fwd(cfg->transform[j], cur[j]); z[j] = host_normal(ckey, (uint32_t)i, (uint32_t)j); }
+        for (int a = 0; a < p; a++) { double s = ztr[a]; for (int k = 0; k <= a; k++) s += L[a * p + k] * z[k]; prop[a] = tr_back(cfg->transform[a], s); }   // :424-432
+        bool finite = true;
+        for (int j = 0; j < p; j++) { lp_prop[j] = log_prior(cfg->prior_kind[j], cfg->prior_a[j], cfg->prior_b[j], prop[j]); if (!isfinite(lp_prop[j])) finite = false; }
+        if (!finite) { store(i); continue; }                                             // :435-442
+        rc = run_pf(prop, se_prop, (unsigned)i);                                         // :445-457
+        if (rc) return rc;
+        const double prop_ll = ll;
+        double lj_prop = 0, lj_cur = 0, slp_prop = 0, slp_cur = 0;
+        for (int j = 0; j < p; j++) {
+            lj_prop += tr_logjac(cfg->transform[j], prop[j]); lj_cur += tr_logjac(cfg->transform[j], cur[j]);   // :461-469
+            slp_prop += lp_prop[j]; slp_cur += log_prior(cfg->prior_kind[j], cfg->prior_a[j], cfg->prior_b[j], cur[j]);
+        }
+        double lar = (prop_ll + slp_prop + lj_prop) - (cur_ll + slp_cur + lj_cur);       // :475-486
+        if (isnan(lar)) lar = -INFINITY;                                                 // :488-490
+        if (log(host_uniform(ckey, (uint32_t)i)) < lar) { cur = prop; cur_ll = prop_ll; se_cur = se_prop; accepted++; }   // :492-496
+        store(i);
+    }
+    if (res->accepted) *res->accepted = accepted;
+    if (res->device_ms) *res->device_ms = ms_total;
+    return BSSM_OK;
+}

@@ -1,0 +1,118 @@
+// rng.h -- counter-based random draws for the device filter ("throughput mode").
+//
+// The reference draws from R's global Mersenne-Twister inside user closures
+// (rnorm in transition_fn / init_fn; R::runif / Rcpp::runif in
+// src/resampling.cpp:28,55).  A sequential generator cannot feed 2^20 lanes,
+// so the device path keys every draw by WHAT it is for instead of WHEN it is
+// drawn:   Philox4x32-10( key = seed,  counter = (index, call, purpose, 0) ).
+// Results therefore do not depend on launch geometry, GPU count or chain
+// placement (mirrors tests/testthat/test-pmmh.R:499-503: 1 core == 2 cores).
+// In "parity mode" the same draws are supplied as arrays instead (and this
+// header's stream can be dumped with bssm_dump_* to feed the CPU oracle).
+//
+// Philox4x32-10: Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy
+// as 1, 2, 3" (SC'11).  Normal deviates by inversion (as R's default
+// "Inversion" normal.kind does) with Wichura's AS 241 PPND16 rational
+// approximation (Appl. Statist. 37 (1988) 477-484).
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define BSSM_HD __host__ __device__ __forceinline__
+#else
+#define BSSM_HD inline
+#endif
+
+namespace bssm {
+
+enum : uint32_t { DRAW_INIT = 1, DRAW_TRANS = 2, DRAW_RESAMPLE = 3, DRAW_PROPOSAL = 5, DRAW_ACCEPT = 6 };
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+BSSM_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+BSSM_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = mulhi32(M0, c.x), lo0 = M0 * c.x;
+        const uint32_t hi1 = mulhi32(M1, c.z), lo1 = M1 * c.z;
+        u32x4 n;
+        n.x = hi1 ^ c.y ^ k0; n.y = lo1; n.z = hi0 ^ c.w ^ k1; n.w = lo0;
+        c = n;
+        k0 += W0; k1 += W1;
+    }
+    return c;
+}
+
+// 64 random bits -> uniform strictly inside (0,1): (k + 1/2) * 2^-53, k in [0, 2^53)
+BSSM_HD double u01_from_bits(uint32_t lo, uint32_t hi)
+{
+    const uint64_t b = ((uint64_t)hi << 32) | lo;
+    return ((double)(b >> 11) + 0.5) * 0x1.0p-53;
+}
+
+// AS 241 PPND16: standard normal quantile, |rel err| ~ 1e-16
+BSSM_HD double qnorm_as241(double p)
+{
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        const double num = (((((((2.5090809287301226727e3 * r + 3.3430575583588128105e4) * r + 6.7265770927008700853e4) * r
+                                + 4.5921953931549871457e4) * r + 1.3731693765509461125e4) * r + 1.9715909503065514427e3) * r
+                             + 1.3314166789178437745e2) * r + 3.3871328727963666080e0);
+        const double den = (((((((5.2264952788528545610e3 * r + 2.8729085735721942674e4) * r + 3.9307895800092710610e4) * r
+                                + 2.1213794301586595867e4) * r + 5.3941960214247511077e3) * r + 6.8718700749205790830e2) * r
+                             + 4.2313330701600911252e1) * r + 1.0);
+        return q * num / den;
+    }
+    double r = (q < 0) ? p : (1.0 - p);
+    r = sqrt(-log(r));
+    double val;
+    if (r <= 5.0) {
+        r -= 1.6;
+        const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r
+                                + 1.27045825245236838258e0) * r + 3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r
+                             + 4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+        const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r
+                                + 1.48103976427480074590e-1) * r + 6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r
+                             + 2.05319162663775882187e0) * r + 1.0);
+        val = num / den;
+    } else {
+        r -= 5.0;
+        const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r
+                                + 2.65321895265761230930e-2) * r + 2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r
+                             + 5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+        const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r
+                                + 7.86869131145613259100e-4) * r + 1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r
+                             + 5.99832206555887937690e-1) * r + 1.0);
+        val = num / den;
+    }
+    return (q < 0) ? -val : val;
+}
+
+struct PhiloxKey { uint32_t k0, k1, stream; };   // key = seed; stream goes into counter word 3
+
+// Two standard normals for the index PAIR (2*pair, 2*pair+1), dimension `dim`,
+// of draw-call `call` with the given purpose.
+BSSM_HD void normal_pair(PhiloxKey key, uint32_t purpose, uint32_t call, uint32_t dim, uint32_t pair,
+                         double& z0, double& z1)
+{
+    u32x4 c; c.x = pair; c.y = call; c.z = purpose | (dim << 8); c.w = key.stream;
+    const u32x4 r = philox4x32_10(c, key.k0, key.k1);
+    z0 = qnorm_as241(u01_from_bits(r.x, r.y));
+    z1 = qnorm_as241(u01_from_bits(r.z, r.w));
+}
+
+// Uniform (0,1) for output index i of resample call `call` (stratified /
+// multinomial); systematic uses index 0.
+BSSM_HD double resample_uniform(PhiloxKey key, uint32_t call, uint32_t i)
+{
+    u32x4 c; c.x = i >> 1; c.y = call; c.z = DRAW_RESAMPLE; c.w = key.stream;
+    const u32x4 r = philox4x32_10(c, key.k0, key.k1);
+    return (i & 1) ? u01_from_bits(r.z, r.w) : u01_from_bits(r.x, r.y);
+}
+
+}  // namespace bssm

@@ -1,0 +1,144 @@
+"""bootstrap_filter / auxiliary_filter: Python mirror of R/bootstrap_filter.R:129-171,
+R/auxiliary_filter.R:163-216 and .particle_filter_core (R/particle_filter_core.R:19-267),
+executed on the GPU by bssm_pf_run."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, models
+
+_RESAMPLE_ALGORITHMS = ("SISAR", "SISR", "SIS")
+_RESAMPLE_FNS = ("stratified", "systematic", "multinomial")
+
+
+def _match_arg(value, choices, name):
+    if value is None:
+        return choices[0]
+    if value not in choices:
+        raise ValueError("'%s' should be one of %s" % (name, ", ".join('"%s"' % c for c in choices)))   # match.arg
+    return value
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def noise_shape(algorithm, T, obs_times=None):
+    ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
+    mt, mr = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.load().bssm_pf_noise_shape(_lib.ALGORITHM[algorithm], int(T), _ptr(ot), C.byref(mt), C.byref(mr)))
+    return mt.value, mr.value
+
+
+def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_times=None,
+                         resample_algorithm="SISAR", resample_fn="stratified", threshold=None,
+                         return_particles=True, return_ancestors=False, seed=0, stream=0, draws=None, ctx=None):
+    """.particle_filter_core on the device.  `draws` (parity mode) = dict(z_init, z_trans, u_res)
+    of injected random draws; otherwise the device generator keyed by (seed, stream) is used."""
+    if not (isinstance(num_particles, (int, np.integer)) and num_particles > 0):
+        raise ValueError("Assertion on 'num_particles' failed: Must be a positive count")      # assert_count :33
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError("this build supports scalar observations (y a vector)")
+    if not np.all(np.isfinite(y)):
+        raise ValueError("Assertion on 'y' failed: Contains missing values")                    # assert_numeric :69
+    T = int(y.size)
+    N = int(num_particles)
+    ot = None
+    if obs_times is not None:
+        ot = np.ascontiguousarray(obs_times, dtype=np.int32)
+        if ot.size != T or (T and (ot[0] < 1 or np.any(np.diff(ot) < 0))):
+            raise ValueError("Assertion on 'obs_times' failed")                                  # assert_integerish :73
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    ctx = ctx or _lib.default_context(N)
+    if ctx.max_particles < N:
+        ctx = _lib.default_context(N)
+    max_trans, max_res = noise_shape(algorithm, T, ot)
+    state_est = np.zeros(T + 1)
+    ess = np.zeros(T + 1)
+    llh = np.zeros(max(T, 1))
+    ll = np.zeros(1)
+    ers = np.zeros(1, dtype=np.int32)
+    nres = np.zeros(1, dtype=np.int32)
+    resampled = np.zeros(max(T, 1), dtype=np.int32)
+    anc = np.zeros((max(max_res, 1), N), dtype=np.int32) if return_ancestors else None
+    ph = np.zeros((T + 1, N)) if return_particles else None
+    wh = np.zeros((T + 1, N)) if return_particles else None
+    ms = np.zeros(1)
+    zi = zt = ur = None
+    if draws is not None:
+        zi = np.ascontiguousarray(draws["z_init"], dtype=np.float64)
+        zt = np.ascontiguousarray(draws["z_trans"], dtype=np.float64)
+        ur = np.ascontiguousarray(draws["u_res"], dtype=np.float64)
+        assert zi.size >= N and zt.size >= max_trans * N
+        assert ur.size >= max_res * (1 if resample_fn == "systematic" else N)
+    cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
+                        _lib.RESAMPLE_FN[resample_fn], N, T, -1.0 if threshold is None else float(threshold),
+                        _ptr(theta), int(theta.size), _ptr(y), _ptr(ot), int(seed), int(stream),
+                        _ptr(zi), _ptr(zt), _ptr(ur), 1 if return_particles else 0, 1 if return_ancestors else 0)
+    res = _lib.PfResult(_ptr(state_est), _ptr(ess), _ptr(llh), _ptr(ll), _ptr(ers), _ptr(nres), _ptr(resampled),
+                        _ptr(anc), _ptr(ph), _ptr(wh), _ptr(ms))
+    st = _lib.load().bssm_pf_run(ctx.handle, C.byref(cfg), C.byref(res))
+    if st in (_lib.ERR_NEGATIVE, _lib.ERR_ZERO_SUM):
+        raise ValueError(_lib.load().bssm_status_string(st).decode())
+    _lib.check(st)
+    out = {"state_est": state_est, "ess": ess, "loglike": float(ll[0]), "loglike_history": llh[:T],
+           "algorithm": algorithm}
+    early = int(ers[0])
+    if early == 0:
+        out["resample_algorithm"] = resample_algorithm        # absent on the degenerate early return (:192-196)
+    if return_particles:
+        rows = early if early else T + 1                      # histories end where the reference returned
+        out["particles_history"] = ph[:rows]
+        out["weights_history"] = wh[:rows]
+    # extras (not in the reference's list): diagnostics for tests and benches
+    out["_extras"] = {"device_ms": float(ms[0]), "n_res_calls": int(nres[0]), "early_return_step": early,
+                      "resampled": resampled[:T]}
+    if return_ancestors:
+        out["_extras"]["ancestors"] = anc[: int(nres[0])]
+    return out
+
+
+def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn, obs_times=None,
+                     resample_algorithm=None, resample_fn=None, threshold=None, return_particles=True, **kwargs):
+    """bootstrap_filter (R/bootstrap_filter.R:129-171).  Model parameters are passed by name
+    (phi=, sigma_x=, sigma_y=), as through `...` in the reference.  Extra keywords of this
+    build: seed, stream, draws, ctx, return_ancestors."""
+    resample_algorithm = _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")
+    resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
+    model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
+    theta = models.theta_from_kwargs((init_fn, transition_fn, log_likelihood_fn), kwargs)
+    return particle_filter_core(y, num_particles, model, theta, "BPF", obs_times, resample_algorithm, resample_fn,
+                                threshold, return_particles, **ctl)
+
+
+def auxiliary_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn,
+                     obs_times=None, resample_algorithm=None, resample_fn=None, threshold=None,
+                     return_particles=True, **kwargs):
+    """auxiliary_filter (R/auxiliary_filter.R:163-216)."""
+    resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    resample_algorithm = _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")
+    ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
+    model = models.resolve(init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn)
+    theta = models.theta_from_kwargs((init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn), kwargs)
+    return particle_filter_core(y, num_particles, model, theta, "APF", obs_times, resample_algorithm, resample_fn,
+                                threshold, return_particles, **ctl)
+
+
+def dump_draws(algorithm, T, N, resample_fn, seed, stream, obs_times=None, ctx=None):
+    """The device generator's draws for one filter run, as arrays a CPU run can consume
+    (same layout as the `draws` argument)."""
+    ctx = ctx or _lib.default_context(N)
+    lib = _lib.load()
+    max_trans, max_res = noise_shape(algorithm, T, obs_times)
+    zi = np.empty(N)
+    _lib.check(lib.bssm_dump_normals(ctx.handle, seed, stream, 1, 0, N, _ptr(zi)))
+    zt = np.empty((max(max_trans, 1), N))
+    for k in range(max_trans):
+        _lib.check(lib.bssm_dump_normals(ctx.handle, seed, stream, 2, k, N, _ptr(zt[k])))
+    nu = 1 if resample_fn == "systematic" else N
+    ur = np.empty((max(max_res, 1), nu))
+    for k in range(max_res):
+        _lib.check(lib.bssm_dump_uniforms(ctx.handle, seed, stream, k, nu, _ptr(ur[k])))
+    return {"z_init": zi, "z_trans": zt, "u_res": ur.reshape(-1) if nu == 1 else ur}

@@ -1,0 +1,243 @@
+"""pmmh(): Python mirror of R/pmmh.R:243-630 for the device path.
+
+The per-chain Metropolis-Hastings loop (R/pmmh.R:422-500) runs natively in
+bssm_pmmh_chain; this module validates arguments, distributes independent
+chains over the GPUs of one node (one process per GPU, torch.distributed), and
+collects theta_chain with ONE all_gather (RCCL over xGMI on the GPU box, gloo
+in the CPU tests) -- the counterpart of future_lapply + bind_rows
+(R/pmmh.R:511-535,596-597).
+"""
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+
+from . import _lib, diagnostics, models
+from .filters import bootstrap_filter, auxiliary_filter, _match_arg, _RESAMPLE_ALGORITHMS, _RESAMPLE_FNS
+
+
+class Prior:
+    def __init__(self, kind, a=0.0, b=1.0):
+        self.kind, self.a, self.b = kind, float(a), float(b)
+
+
+def prior_normal(mean=0.0, sd=1.0):
+    """function(x) dnorm(x, mean, sd, log = TRUE)"""
+    return Prior("normal", mean, sd)
+
+
+def prior_exponential(rate=1.0):
+    """function(x) dexp(x, rate, log = TRUE)"""
+    return Prior("exponential", rate, 0.0)
+
+
+def prior_uniform(lo=0.0, hi=1.0):
+    """function(x) dunif(x, lo, hi, log = TRUE)"""
+    return Prior("uniform", lo, hi)
+
+
+def prior_flat():
+    """function(x) 0"""
+    return Prior("flat")
+
+
+def default_tune_control(pilot_proposal_sd=0.5, pilot_n=100, pilot_m=2000, pilot_target_var=1, pilot_burn_in=500,
+                         pilot_reps=100, pilot_resample_algorithm="SISAR", pilot_resample_fn="stratified"):
+    """default_tune_control (R/pmmh.R:33-58): same defaults, same checks."""
+    if not (np.isfinite(pilot_proposal_sd) and pilot_proposal_sd >= 0):
+        raise ValueError("Assertion on 'pilot_proposal_sd' failed")
+    for name, v in (("pilot_n", pilot_n), ("pilot_m", pilot_m), ("pilot_burn_in", pilot_burn_in), ("pilot_reps", pilot_reps)):
+        if not (isinstance(v, (int, np.integer)) and v > 0):
+            raise ValueError("Assertion on '%s' failed: Must be a positive count" % name)
+    if not (np.isfinite(pilot_target_var) and pilot_target_var >= 0):
+        raise ValueError("Assertion on 'pilot_target_var' failed")
+    return {"pilot_proposal_sd": pilot_proposal_sd, "pilot_n": pilot_n, "pilot_m": pilot_m,
+            "pilot_target_var": pilot_target_var, "pilot_burn_in": pilot_burn_in, "pilot_reps": pilot_reps,
+            "pilot_resample_algorithm": _match_arg(pilot_resample_algorithm, _RESAMPLE_ALGORITHMS, "pilot_resample_algorithm"),
+            "pilot_resample_fn": _match_arg(pilot_resample_fn, _RESAMPLE_FNS, "pilot_resample_fn")}
+
+
+def chain_assignment(num_chains, world_size):
+    """chain c (0-based) -> rank c mod world_size: whole chains per GPU, no data-path collective."""
+    return [[c for c in range(num_chains) if c % world_size == r] for r in range(world_size)]
+
+
+def gather_chains(local, num_chains, m, p, dist=None):
+    """Collect {chain index: (m x p) array} from every rank into one (num_chains, m, p) array with
+    a single all_gather; identity when torch.distributed is not initialised."""
+    out = np.full((num_chains, m, p), np.nan)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        for c, a in local.items():
+            out[c] = a
+        return out
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = (num_chains + world - 1) // world
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    buf = torch.full((per, m, p), float("nan"), dtype=torch.float64)
+    for slot, c in enumerate(chain_assignment(num_chains, world)[rank]):
+        buf[slot] = torch.from_numpy(np.ascontiguousarray(local[c]))
+    buf = buf.to(dev)
+    allbuf = torch.empty((world, per, m, p), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allbuf, buf)
+    allbuf = allbuf.cpu().numpy()
+    for r, chains in enumerate(chain_assignment(num_chains, world)):
+        for slot, c in enumerate(chains):
+            out[c] = allbuf[r, slot]
+    return out
+
+
+def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov, transform, priors, num_particles,
+                     seed, chain_index, obs_times=None, resample_algorithm="SISAR", resample_fn="stratified",
+                     return_latent_state_est=False, ctx=None):
+    """One chain of R/pmmh.R:403-415,422-500 on this process's GPU (bssm_pmmh_chain)."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    T = y.size
+    ctx = ctx or _lib.default_context(num_particles)
+    if ctx.max_particles < num_particles:
+        ctx = _lib.default_context(num_particles)
+    ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
+    algorithm = "APF" if pf_wrapper is auxiliary_filter else "BPF"
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None   # noqa: E731
+    init_theta = np.ascontiguousarray(init_theta, dtype=np.float64)
+    cov = np.ascontiguousarray(proposal_cov, dtype=np.float64).reshape(n_params, n_params)
+    tr = np.ascontiguousarray([_lib.TRANSFORM[t] for t in transform], dtype=np.int32)
+    pk = np.ascontiguousarray([_lib.PRIOR[p.kind] for p in priors], dtype=np.int32)
+    pa = np.ascontiguousarray([p.a for p in priors], dtype=np.float64)
+    pb = np.ascontiguousarray([p.b for p in priors], dtype=np.float64)
+    pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
+                       _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, None, n_params, ptr(y), ptr(ot),
+                       int(seed), 0, None, None, None, 0, 0)
+    cfg = _lib.PmmhConfig(pf, int(m), int(n_params), ptr(init_theta), ptr(cov), ptr(tr), ptr(pk), ptr(pa), ptr(pb),
+                          int(seed), int(chain_index), 1 if return_latent_state_est else 0)
+    theta_chain = np.zeros((m, n_params))
+    ll_chain = np.zeros(m)
+    se_chain = np.zeros((m, T + 1)) if return_latent_state_est else None
+    acc = np.zeros(1, dtype=np.int32)
+    ms = np.zeros(1)
+    res = _lib.PmmhResult(ptr(theta_chain), ptr(ll_chain), ptr(se_chain), ptr(acc), ptr(ms))
+    _lib.check(_lib.load().bssm_pmmh_chain(ctx.handle, C.byref(cfg), C.byref(res)))
+    return {"theta_chain": theta_chain, "loglike_chain": ll_chain, "state_est_chain": se_chain,
+            "accepted": int(acc[0]), "device_ms": float(ms[0])}
+
+
+def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors, pilot_init_params, burn_in,
+         num_chains=4, obs_times=None, resample_algorithm=None, resample_fn=None, param_transform=None,
+         tune_control=None, verbose=False, return_latent_state_est=False, seed=None, num_cores=1,
+         num_particles=None, proposal_cov=None, _chain_runner=None, **kwargs):
+    """pmmh (R/pmmh.R:243-630) on the device path.
+
+    Deviations from the reference, both stated in DESIGN.md:
+      * `num_particles` / `proposal_cov` override the pilot's target_n (capped at 1000 in the reference,
+        R/pmmh_tuning.R:55-57) and pilot covariance; the pilot run itself is not part of this build yet,
+        so both are REQUIRED.  The chain starts at pilot_init_params[[chain]].
+      * as in the reference, `resample_algorithm` / `resample_fn` are validated but NOT forwarded to the
+        main chain's filter calls (R/pmmh.R:403-415; tests/testthat/test-pmmh.R:404-466): the wrapper
+        defaults (SISAR, stratified) apply, unless `pf_resample_algorithm` / `pf_resample_fn` are given.
+    """
+    tune_control = tune_control or default_tune_control()
+    y = np.asarray(y, dtype=np.float64)
+    if not np.all(np.isfinite(y)):
+        raise ValueError("Assertion on 'y' failed: Contains missing values")
+    if not (isinstance(m, (int, np.integer)) and m >= 1):
+        raise ValueError("Assertion on 'm' failed: Must be >= 1")
+    if not (isinstance(burn_in, (int, np.integer)) and 0 <= burn_in <= m - 1):
+        raise ValueError("Assertion on 'burn_in' failed")
+    if not (isinstance(num_chains, (int, np.integer)) and num_chains >= 1):
+        raise ValueError("Assertion on 'num_chains' failed: Must be >= 1")
+    if not (isinstance(pilot_init_params, (list, tuple)) and len(pilot_init_params) == num_chains):
+        raise ValueError("Assertion on 'pilot_init_params' failed: Must have length %d" % num_chains)
+    names0 = list(pilot_init_params[0].keys())
+    for pinit in pilot_init_params:
+        if list(pinit.keys()) != names0:
+            raise ValueError("Assertion on 'pilot_init_params' failed: Must be TRUE")
+    if len(names0) == 0:
+        raise ValueError("pilot_init_params must contain at least one parameter.")
+    # .check_params_match (R/utils.R:15-72)
+    model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
+    fn_params = []
+    for fn in (init_fn, transition_fn, log_likelihood_fn):
+        for a in fn.formals():
+            if a not in ("num_particles", "particles", "y", "t", "...") and a not in fn_params:
+                fn_params.append(a)
+    if not all(p in names0 for p in fn_params):
+        raise ValueError("Parameters in functions do not match the names in pilot_init_params")
+    if not all(p in log_priors for p in fn_params):
+        raise ValueError("Parameters in functions do not match the names in log_priors")
+    _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")   # validated, not forwarded
+    _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    prior_names = list(log_priors.keys())
+    if param_transform is None:
+        param_transform = {k: "identity" for k in prior_names}
+    elif isinstance(param_transform, dict):
+        if not all(k in param_transform for k in prior_names):
+            raise ValueError("param_transform must include an entry for every parameter in log_priors.")
+        bad = [k for k, v in param_transform.items() if v not in ("log", "logit", "identity")]
+        if bad:
+            warnings.warn("Only 'log', 'logit', and 'identity' transformations are supported. "
+                          "Using 'identity' for invalid entries.")
+            param_transform = dict(param_transform, **{k: "identity" for k in bad})
+    else:
+        raise ValueError("param_transform must be a list.")
+    if prior_names != list(models.Model.PARAM_ORDER):
+        raise ValueError("log_priors must be given in the order %s for the built-in models" % (models.Model.PARAM_ORDER,))
+    transform = [param_transform[k] for k in prior_names]
+    priors = [log_priors[k] for k in prior_names]
+    if num_particles is None or proposal_cov is None:
+        raise NotImplementedError(
+            "pilot tuning (.run_pilot_chain, R/pmmh_tuning.R) is not part of this build: pass num_particles= and "
+            "proposal_cov= (SURVEY.md 8f-1)")
+    if seed is None:
+        seed = int(np.random.default_rng().integers(1, 2 ** 31 - 1))
+    # per-chain seeds drawn up-front, so results do not depend on how chains are placed (R/pmmh.R:511)
+    seeds = np.random.default_rng(seed).integers(1, 2 ** 31 - 1, size=num_chains)
+
+    dist = None
+    try:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            dist = tdist
+    except Exception:
+        dist = None
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    mine = chain_assignment(num_chains, world)[rank]
+    n_params = len(prior_names)
+    local, extras = {}, {}
+    pf_ra = kwargs.pop("pf_resample_algorithm", "SISAR")
+    pf_rf = kwargs.pop("pf_resample_fn", "stratified")
+    for c in mine:
+        init_theta = [float(pilot_init_params[c][k]) for k in prior_names]
+        if verbose:
+            print("Running chain %d..." % (c + 1))
+        runner = _chain_runner or run_chain_device
+        r = runner(pf_wrapper=pf_wrapper, y=y, m=m, model=model, n_params=n_params, init_theta=init_theta,
+                   proposal_cov=proposal_cov, transform=transform, priors=priors, num_particles=num_particles,
+                   seed=int(seeds[c]), chain_index=c, obs_times=obs_times, resample_algorithm=pf_ra,
+                   resample_fn=pf_rf, return_latent_state_est=return_latent_state_est)
+        local[c] = r["theta_chain"]
+        extras[c] = r
+    chains = gather_chains(local, num_chains, m, n_params, dist)          # (num_chains, m, p)
+    post = chains[:, burn_in:, :]                                         # drop burn-in (R/pmmh.R:540-545)
+    diag_ess, diag_rhat = {}, {}
+    for j, name in enumerate(prior_names):
+        mat = post[:, :, j].T                                             # iterations x chains
+        diag_ess[name] = diagnostics.ess(mat) if num_chains > 1 else float("nan")
+        diag_rhat[name] = diagnostics.rhat(mat)
+    result = {
+        "theta_chain": {"chain": np.repeat(np.arange(1, num_chains + 1), m - burn_in),
+                        **{name: post[:, :, j].reshape(-1) for j, name in enumerate(prior_names)}},
+        "diagnostics": {"ess": diag_ess, "rhat": diag_rhat},
+        "_extras": {"local_chains": extras, "seeds": seeds, "rank": rank, "world_size": world},
+    }
+    if return_latent_state_est:
+        result["latent_state_chain"] = {c: extras[c]["state_est_chain"][burn_in:] for c in mine}
+    if any(np.isfinite(v) and v < 400 for v in diag_ess.values()):
+        warnings.warn("Some ESS values are below 400, indicating poor mixing. "
+                      "Consider running the chains for more iterations.")
+    if any(np.isfinite(v) and v > 1.01 for v in diag_rhat.values()):
+        warnings.warn("\nSome Rhat values are above 1.01, indicating that the chains have not converged. \n"
+                      "Consider running the chains for more iterations and/or increase burn_in.")
+    return result

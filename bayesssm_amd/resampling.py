@@ -1,0 +1,94 @@
+"""Resamplers: Python mirror of R/RcppExports.R:4-14 and R/resampling.R:13-69,
+running on the GPU through the C ABI (bssm_resample_*)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_rng = np.random.default_rng()
+
+
+def set_seed(seed):
+    """Seeds the host generator that stands in for R's global RNG (set.seed)
+    for the uniform draws of the resamplers."""
+    global _rng
+    _rng = np.random.default_rng(seed)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _resample(kind, n, weights, U, ctx, return_cum=False, return_stats=False):
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    n = int(n)
+    nw = int(w.size)
+    ctx = ctx or _lib.default_context(max(n, nw))
+    if ctx.max_particles < max(n, nw):
+        ctx = _lib.default_context(max(n, nw))
+    U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1)
+    need = 1 if kind == "systematic" else n
+    if U.size < need:
+        raise ValueError("need %d uniform draws, got %d" % (need, U.size))
+    out = np.empty(n, dtype=np.int32)
+    cum = np.empty(nw, dtype=np.float64) if return_cum else None
+    stats = np.zeros(4, dtype=np.int64)
+    st = _lib.load().bssm_resample_ex(ctx.handle, _lib.RESAMPLE_FN[kind], n, _ptr(w), nw, _ptr(U), _ptr(out),
+                                      _ptr(cum) if cum is not None else None, _ptr(stats))
+    if st in (_lib.ERR_NEGATIVE, _lib.ERR_ZERO_SUM):
+        raise ValueError(_lib.load().bssm_status_string(st).decode())     # Rcpp::stop -> R error
+    _lib.check(st)
+    res = (out,)
+    if return_cum:
+        res += (cum,)
+    if return_stats:
+        res += (stats,)
+    return res if len(res) > 1 else out
+
+
+def resample_systematic_cpp(n, weights, U=None, ctx=None, **kw):
+    """resample_systematic_cpp(n, weights) (src/resampling.cpp:43-66).  U: the R::runif(0,1) draw."""
+    if U is None:
+        U = _rng.random()
+    return _resample("systematic", n, weights, [U], ctx, **kw)
+
+
+def resample_stratified_cpp(n, weights, U=None, ctx=None, **kw):
+    """resample_stratified_cpp(n, weights) (src/resampling.cpp:16-40).  U: the Rcpp::runif(n) draws."""
+    if U is None:
+        U = _rng.random(int(n))
+    return _resample("stratified", n, weights, U, ctx, **kw)
+
+
+def resample_multinomial_cpp(n, weights, U=None, ctx=None, **kw):
+    """resample_multinomial_cpp(n, weights) (src/resampling.cpp:5-13); inverse-CDF draws
+    (distributional parity with Rcpp::sample only)."""
+    if U is None:
+        U = _rng.random(int(n))
+    return _resample("multinomial", n, weights, U, ctx, **kw)
+
+
+def _shim(cpp, particles, weights, U, ctx):
+    particles = np.asarray(particles)
+    weights = np.asarray(weights, dtype=np.float64)
+    n = particles.shape[0]
+    if n != weights.size:
+        raise ValueError("Number of particles must match the length of weights")   # R/resampling.R:17,24
+    idx = cpp(n, weights, U=U, ctx=ctx)
+    return particles[idx - 1]           # particles[indices, , drop = FALSE] / particles[indices]
+
+
+def resample_multinomial(particles, weights, U=None, ctx=None):
+    """.resample_multinomial (R/resampling.R:13-29)."""
+    return _shim(resample_multinomial_cpp, particles, weights, U, ctx)
+
+
+def resample_stratified(particles, weights, U=None, ctx=None):
+    """.resample_stratified (R/resampling.R:33-49)."""
+    return _shim(resample_stratified_cpp, particles, weights, U, ctx)
+
+
+def resample_systematic(particles, weights, U=None, ctx=None):
+    """.resample_systematic (R/resampling.R:53-69)."""
+    return _shim(resample_systematic_cpp, particles, weights, U, ctx)

@@ -1,0 +1,202 @@
+/*
+ * bayesssm_amd.h -- C ABI of the MI355X particle-filter engine.
+ *
+ * This is the drop-in boundary for bayesSSM's hot path.  Every entry point is
+ * `extern "C"`, takes plain pointers/sizes and returns an int status
+ * (BSSM_OK == 0); `bssm_last_error()` gives the message of the last failure on
+ * the calling thread.  Nothing here throws, and no torch/R types appear.
+ *
+ * What each group replaces in the reference (paths relative to the bayesSSM
+ * checkout):
+ *
+ *   bssm_resample_*        SEXP _bayesSSM_resample_{multinomial,stratified,systematic}_cpp
+ *                          (SEXP nSEXP, SEXP weightsSEXP)      src/RcppExports.cpp:15,27,39
+ *                          = resample_*_cpp(n, weights)        src/resampling.cpp:5,16,43
+ *                          called from .resample_*             R/resampling.R:19,39,59
+ *   bssm_pf_run            .particle_filter_core               R/particle_filter_core.R:19-267
+ *                          via bootstrap_filter / auxiliary_filter
+ *                                                              R/bootstrap_filter.R:129-171
+ *                                                              R/auxiliary_filter.R:163-216
+ *   bssm_pmmh_chain        the per-chain loop of pmmh()        R/pmmh.R:403-415,422-500
+ *                          (+ R/utils.R:102-152 transforms)
+ *
+ * Random draws.  The reference takes them from R's global RNG
+ * (Rcpp::RNGScope, src/RcppExports.cpp:18,30,42).  Here they are either
+ * INPUTS (the R glue / the parity tests draw them and pass them in) or, when
+ * the pointers are NULL, generated on the device by a counter-based generator
+ * keyed by (seed, stream) -- see csrc/rng.h.
+ *
+ * Indices returned to the caller are 1-based int32, as the reference's
+ * IntegerVector is (src/resampling.cpp:36,62).
+ */
+#ifndef BAYESSSM_AMD_H
+#define BAYESSSM_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+#define BSSM_OK 0
+#define BSSM_ERR_NEGATIVE_WEIGHT 1   /* "Weights must be non-negative"          src/resampling.cpp:6,18,45 */
+#define BSSM_ERR_ZERO_SUM 2          /* "Sum of weights must be greater than 0" src/resampling.cpp:8,22,49 */
+#define BSSM_ERR_LENGTH 3            /* "Number of particles must match the length of weights" R/resampling.R:17 */
+#define BSSM_ERR_ARG 4               /* invalid argument (message says which)   */
+#define BSSM_ERR_HIP 5               /* HIP runtime failure                     */
+#define BSSM_ERR_CAPACITY 6          /* problem larger than the context was created for */
+
+/* ---- enums (values match the oracle's) ---------------------------------- */
+#define BSSM_MODEL_LG 0       /* x' = phi x + N(0,sx);            y ~ N(x, sy)   tests/testthat/test-pmmh_tuning.R:163-173 */
+#define BSSM_MODEL_AR1SIN 1   /* x' = phi x + sin x + N(0,sx);    y ~ N(x, sy)   README.md:137-146 */
+
+#define BSSM_BPF 0            /* bootstrap_filter  */
+#define BSSM_APF 1            /* auxiliary_filter  */
+
+#define BSSM_SIS 0
+#define BSSM_SISR 1
+#define BSSM_SISAR 2
+
+#define BSSM_STRATIFIED 0
+#define BSSM_SYSTEMATIC 1
+#define BSSM_MULTINOMIAL 2
+
+#define BSSM_TR_IDENTITY 0
+#define BSSM_TR_LOG 1
+#define BSSM_TR_LOGIT 2
+
+#define BSSM_PRIOR_NORMAL 0   /* dnorm(x, a, b, log=TRUE)  */
+#define BSSM_PRIOR_EXP 1      /* dexp(x, rate=a, log=TRUE) */
+#define BSSM_PRIOR_UNIFORM 2  /* dunif(x, a, b, log=TRUE)  */
+#define BSSM_PRIOR_FLAT 3     /* 0                          */
+
+typedef struct bssm_ctx bssm_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+/* One context per GPU (and per host thread that drives it).  Owns all device
+ * memory for filters of up to `max_particles` particles of dimension
+ * `max_dim`, and one HIP stream. */
+int bssm_ctx_create(int device, long long max_particles, int max_dim, bssm_ctx** out);
+void bssm_ctx_destroy(bssm_ctx* ctx);
+const char* bssm_last_error(void);
+const char* bssm_status_string(int status);   /* the reference's error text for a status */
+int bssm_device_count(void);
+int bssm_ctx_synchronize(bssm_ctx* ctx);
+/* The HIP stream (hipStream_t) all of this context's kernels are launched on. */
+void* bssm_ctx_stream(bssm_ctx* ctx);
+
+/* ---- resamplers: host-pointer form (what the R glue binds) --------------- */
+/* n outputs over nw weights (the reference always passes n == nw).
+ * U: the uniform draw(s) the reference takes from R's RNG --
+ *   systematic : one double  (R::runif(0,1),   src/resampling.cpp:55)
+ *   stratified : n doubles   (Rcpp::runif(n),  src/resampling.cpp:28)
+ *   multinomial: n doubles   (inverse-CDF draws; distributional parity only,
+ *                             the reference uses Rcpp::sample)
+ * indices_out: n int32, 1-based. */
+int bssm_resample_systematic(bssm_ctx* ctx, int n, const double* weights, int nw, double U, int* indices_out);
+int bssm_resample_stratified(bssm_ctx* ctx, int n, const double* weights, int nw, const double* U, int* indices_out);
+int bssm_resample_multinomial(bssm_ctx* ctx, int n, const double* weights, int nw, const double* U, int* indices_out);
+
+/* Device-pointer form: weights / U / indices already in HBM; runs on the
+ * context's stream and does not synchronise.  kind = BSSM_STRATIFIED/... ;
+ * d_U may be NULL for systematic (then U_scalar is used).  cum_out (optional,
+ * device, nw doubles) receives the exact sequential cumulative sum. */
+int bssm_resample_device(bssm_ctx* ctx, int kind, int n, const double* d_weights, int nw,
+                         double U_scalar, const double* d_U, int* d_indices_out, double* d_cum_out);
+/* Status of the last device-form call (synchronises the stream). */
+int bssm_resample_device_status(bssm_ctx* ctx);
+
+/* Host-pointer form with diagnostics: cum_out (optional, nw doubles) receives
+ * the exact sequential cum_sum of prob = weights/sum(weights)
+ * (src/resampling.cpp:24-25,51-52); stats (optional, 4 long long):
+ * {blocks with a literal tail, serial block walks, literal terms, scan blocks}.
+ * kind = BSSM_STRATIFIED / BSSM_SYSTEMATIC / BSSM_MULTINOMIAL; U as above
+ * (systematic reads U[0]). */
+int bssm_resample_ex(bssm_ctx* ctx, int kind, int n, const double* weights, int nw, const double* U,
+                     int* indices_out, double* cum_out, long long* stats);
+
+/* ---- particle filter ---------------------------------------------------- */
+typedef struct {
+    int model;               /* BSSM_MODEL_*                                   */
+    int algorithm;           /* BSSM_BPF / BSSM_APF                            */
+    int resample_algorithm;  /* BSSM_SIS / SISR / SISAR                        */
+    int resample_fn;         /* BSSM_STRATIFIED / SYSTEMATIC / MULTINOMIAL     */
+    long long num_particles;
+    int T;                   /* number of observations                         */
+    double threshold;        /* < 0: NULL => auto (R/particle_filter_core.R:44-50) */
+    const double* theta;     /* model parameters (host), n_theta doubles       */
+    int n_theta;
+    const double* y;         /* observations (host), T doubles                 */
+    const int* obs_times;    /* host, T ints, or NULL => 1..T                  */
+    unsigned long long seed;     /* device generator key (throughput mode)     */
+    unsigned long long stream;   /* e.g. chain index / iteration               */
+    /* parity mode: injected draws (host pointers); NULL => device generator  */
+    const double* z_init;    /* N standard normals                             */
+    const double* z_trans;   /* [n_trans_calls][N]                             */
+    const double* u_res;     /* systematic [n_res_calls]; else [n_res_calls][N] */
+    int return_particles;    /* fill particles_history / weights_history       */
+    int return_ancestors;    /* fill ancestors                                 */
+} bssm_pf_config;
+
+typedef struct {
+    double* state_est;        /* (T+1) x d                                     */
+    double* ess;              /* T+1                                           */
+    double* loglike_history;  /* T, cumulative (R/particle_filter_core.R:209)  */
+    double* loglike;          /* 1                                             */
+    int* early_return_step;   /* 1: 0 = ran to the end, i = degenerate at obs i (:189-202) */
+    int* n_res_calls;         /* 1                                             */
+    int* resampled;           /* T or NULL: weight-triggered resample ran at obs i */
+    int* ancestors;           /* [max_res_calls][N] 1-based, or NULL           */
+    double* particles_history;/* (T+1) x (N d) row-major rows = as.numeric(N x d), or NULL */
+    double* weights_history;  /* (T+1) x N, or NULL                            */
+    double* device_ms;        /* 1 or NULL: HIP-event time of the run on the stream */
+} bssm_pf_result;
+
+int bssm_pf_run(bssm_ctx* ctx, const bssm_pf_config* cfg, bssm_pf_result* res);
+
+/* Number of transition_fn / resample calls the filter makes at most (sizes of
+ * the injected-draw arrays and of `ancestors`). */
+int bssm_pf_noise_shape(int algorithm, int T, const int* obs_times, int* max_trans, int* max_res);
+
+/* Dump the device generator's draws so a CPU run can consume the same ones
+ * (host output pointers). */
+int bssm_dump_normals(bssm_ctx* ctx, unsigned long long seed, unsigned long long stream,
+                      int purpose /* 1 init, 2 transition */, int call, long long n, double* out);
+int bssm_dump_uniforms(bssm_ctx* ctx, unsigned long long seed, unsigned long long stream,
+                       int call, long long n, double* out);
+
+/* Per-kernel-class device time of the last bssm_pf_run with profiling enabled
+ * (bssm_ctx_set_profile(ctx, 1) inserts HIP events around every launch; slower,
+ * so never inside a timed throughput region).  names: array of const char*. */
+int bssm_ctx_set_profile(bssm_ctx* ctx, int enable);
+int bssm_ctx_get_profile(bssm_ctx* ctx, int max_entries, const char** names, double* total_ms, long long* launches);
+
+/* ---- PMMH: one chain ---------------------------------------------------- */
+typedef struct {
+    bssm_pf_config pf;         /* filter settings; theta/seed/stream are overwritten per iteration */
+    int m;                     /* iterations (rows of theta_chain)                */
+    int n_params;              /* == pf.n_theta                                   */
+    const double* init_theta;  /* starting point (the reference uses the pilot mean, R/pmmh.R:373) */
+    const double* proposal_cov;/* n_params x n_params, on the ORIGINAL scale (pilot covariance, :374) */
+    const int* transform;      /* BSSM_TR_* per parameter                         */
+    const int* prior_kind;     /* BSSM_PRIOR_* per parameter                      */
+    const double* prior_a;     /* per parameter                                   */
+    const double* prior_b;
+    unsigned long long seed;   /* chain seed (R/pmmh.R:346,511)                   */
+    int chain_index;
+    int return_latent_state_est;
+} bssm_pmmh_config;
+
+typedef struct {
+    double* theta_chain;       /* m x n_params, row-major                         */
+    double* loglike_chain;     /* m                                               */
+    double* state_est_chain;   /* m x (T+1), or NULL                              */
+    int* accepted;             /* 1: number of accepted proposals                 */
+    double* device_ms;         /* 1 or NULL: summed filter device time            */
+} bssm_pmmh_result;
+
+int bssm_pmmh_chain(bssm_ctx* ctx, const bssm_pmmh_config* cfg, bssm_pmmh_result* res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYESSSM_AMD_H */

@@ -1,0 +1,119 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/bayesssm_amd.h declares
+(no compute without a GPU), the host mirror validates like the reference, and the product never
+touches oracle/."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "bayesssm_amd", "csrc"), "-s"])
+    from bayesssm_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "bayesssm_amd.h")).read()
+    declared = set(re.findall(r"\b(bssm_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = built.load()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), sym
+    assert declared == set(built.EXPORTED_SYMBOLS)
+
+
+def test_no_cpu_path(built):
+    lib = built.load()
+    if lib.bssm_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(built.BssmError, match="no HIP device"):
+        built.Context()
+    import bayesssm_amd as b
+    with pytest.raises(built.BssmError):
+        b.resample_systematic_cpp(3, [1, 1, 1], U=0.5)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bayesssm_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("CPU oracle", "").replace("the oracle's", "").replace("(values match the oracle", ""), \
+                    os.path.join(dirpath, f)
+
+
+def test_status_strings(built):
+    lib = built.load()
+    assert lib.bssm_status_string(1).decode() == "Weights must be non-negative"
+    assert lib.bssm_status_string(2).decode() == "Sum of weights must be greater than 0"
+    assert lib.bssm_status_string(3).decode() == "Number of particles must match the length of weights"
+
+
+def test_host_validation():
+    import bayesssm_amd as b
+    m = b.models.linear_gaussian()
+    with pytest.raises(ValueError, match="should be one of"):
+        b.bootstrap_filter([0.0], 10, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_fn="bogus",
+                           phi=1, sigma_x=1, sigma_y=1)
+    with pytest.raises(ValueError, match="num_particles"):
+        b.bootstrap_filter([0.0], 0, m.init_fn, m.transition_fn, m.log_likelihood_fn, phi=1, sigma_x=1, sigma_y=1)
+    with pytest.raises(TypeError, match='argument "phi" is missing'):
+        b.bootstrap_filter([0.0], 10, m.init_fn, m.transition_fn, m.log_likelihood_fn, sigma_x=1, sigma_y=1)
+    with pytest.raises(TypeError, match="built-in model descriptor"):
+        b.bootstrap_filter([0.0], 10, lambda n: 0, m.transition_fn, m.log_likelihood_fn, phi=1, sigma_x=1, sigma_y=1)
+    with pytest.raises(ValueError, match="missing values"):
+        b.bootstrap_filter([np.nan], 10, m.init_fn, m.transition_fn, m.log_likelihood_fn, phi=1, sigma_x=1, sigma_y=1)
+    tc = b.default_tune_control()
+    # tests/testthat/test-pmmh.R:5-25
+    assert tc == {"pilot_proposal_sd": 0.5, "pilot_n": 100, "pilot_m": 2000, "pilot_target_var": 1,
+                  "pilot_burn_in": 500, "pilot_reps": 100, "pilot_resample_algorithm": "SISAR",
+                  "pilot_resample_fn": "stratified"}
+    with pytest.raises(ValueError):
+        b.default_tune_control(pilot_n=0)
+
+
+def test_diagnostics_match_oracle(oracle):
+    import bayesssm_amd as b
+    rng = np.random.default_rng(0)
+    x = np.zeros((400, 3))
+    for c in range(3):
+        for i in range(1, 400):
+            x[i, c] = 0.7 * x[i - 1, c] + rng.standard_normal()
+    assert b.ess(x) == pytest.approx(oracle.mcmc_ess(x), rel=1e-9)
+    iid = rng.standard_normal((1000, 4))
+    assert b.rhat(iid) == 1.0 or abs(b.rhat(iid) - 1) < 0.02
+    assert 2500 < b.ess(iid) < 6000
+    with pytest.raises(ValueError, match="at least 2"):
+        b.ess(np.zeros((5, 1)))
+
+
+def test_rng_header_on_host(oracle):
+    """csrc/rng.h compiled for the host: Philox4x32-10 known answers (Random123 kat_vectors) and the
+    AS241 quantile against scipy."""
+    import ctypes as C
+    from scipy import stats
+    src = os.path.join(ROOT, "tests", "harness", "rng_harness.cpp")
+    so = os.path.join(ROOT, "tests", "harness", "_build", "librng_harness.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    lib = C.CDLL(so)
+    out = (C.c_uint32 * 4)()
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        lib.h_philox(*[C.c_uint32(v) for v in ctr], *[C.c_uint32(v) for v in key], out)
+        assert tuple(out) == want
+    lib.h_qnorm.restype = C.c_double
+    lib.h_qnorm.argtypes = [C.c_double]
+    ps = np.concatenate([np.linspace(1e-15, 1 - 1e-15, 2001), 10.0 ** -np.arange(2, 16), [0.5, 0.075, 0.925]])
+    got = np.array([lib.h_qnorm(float(p)) for p in ps])
+    np.testing.assert_allclose(got, stats.norm.ppf(ps), rtol=2e-14, atol=1e-15)

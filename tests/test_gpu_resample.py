@@ -1,0 +1,145 @@
+"""GPU parity tests for the resamplers (through the C ABI): ancestors must be BIT-EXACT against
+the CPU oracle's restatement of src/resampling.cpp for identical (n, weights, uniforms)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def B():
+    import bayesssm_amd as b
+    return b
+
+
+@pytest.fixture(scope="module")
+def ctx(B):
+    return B.Context(0, 1 << 22, 1)
+
+
+def test_error_strings(B, ctx):
+    # tests/testthat/test-resampling.R:2-28
+    for fn, U in ((B.resample_systematic_cpp, 0.5), (B.resample_stratified_cpp, [.5, .5, .5]),
+                  (B.resample_multinomial_cpp, [.5, .5, .5])):
+        with pytest.raises(ValueError, match="Weights must be non-negative"):
+            fn(3, [-1, 1, 2], U=U, ctx=ctx)
+        with pytest.raises(ValueError, match="Sum of weights must be greater than 0"):
+            fn(3, [0, 0, 0], U=U, ctx=ctx)
+    with pytest.raises(ValueError, match="Number of particles must match the length of weights"):
+        B.resample_systematic(np.arange(4), [0.5, 0.5], ctx=ctx)        # R/resampling.R:17; test-resampling.R:71-102
+    with pytest.raises(ValueError, match="Number of particles must match the length of weights"):
+        B.resample_stratified(np.zeros((4, 2)), [0.5, 0.5], ctx=ctx)
+
+
+def test_hand_cases(B, ctx):
+    with open(os.path.join(GOLD, "resample_hand_cases.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        fn = B.resample_systematic_cpp if c["kind"] == "systematic" else B.resample_stratified_cpp
+        got = fn(c["n"], c["weights"], U=c["U"], ctx=ctx)
+        assert got.tolist() == c["expected"], c["name"]
+
+
+def test_reference_kats(B, ctx):
+    # tests/testthat/test-resampling.R:48-68 and :190-202
+    rng = np.random.default_rng(1405)
+    w = [0.1, 0.5, 0.1, 0.15, 0.15]
+    for _ in range(20):
+        s = B.resample_stratified_cpp(5, w, U=rng.random(5), ctx=ctx)
+        assert s[1] == 2 and s[2] == 2
+        y = B.resample_systematic_cpp(5, w, U=rng.random(), ctx=ctx)
+        assert y[1] == 2 and y[2] == 2 and y[3] == (3 if y[0] == 1 else 4)
+    hot = [0, 0, 1, 0, 0]
+    assert (B.resample_systematic(np.arange(1, 6), hot, ctx=ctx) == 3).all()
+    assert (B.resample_stratified(np.arange(1, 6), hot, ctx=ctx) == 3).all()
+    assert (B.resample_multinomial(np.arange(1, 6), hot, ctx=ctx) == 3).all()
+
+
+def _weights(rng, n, kind):
+    if kind == "uniformish":
+        return np.exp(-0.5 * rng.standard_normal(n) ** 2)
+    if kind == "skewed":
+        return rng.random(n) ** 8
+    if kind == "equal":
+        return np.full(n, 1.0 / n)
+    if kind == "sparse":
+        return rng.random(n) * (rng.random(n) < 0.01) + (np.arange(n) == n // 2)
+    if kind == "range":
+        return np.exp(rng.uniform(-300, 0, n))
+    if kind == "ties":
+        w = np.full(n, 2.0 ** -53)
+        w[0] = 0.75
+        return w
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 100, 2047, 2048, 2049, 4097, 65536, 1 << 20])
+@pytest.mark.parametrize("kind", ["uniformish", "skewed", "equal", "sparse"])
+def test_bit_exact_systematic_stratified(B, ctx, oracle, n, kind):
+    rng = np.random.default_rng(n * 7 + len(kind))
+    w = _weights(rng, n, kind)
+    for U in (rng.random(), 0.0):
+        got, cum = B.resample_systematic_cpp(n, w, U=U, ctx=ctx, return_cum=True)
+        want, wcum = oracle.resample_systematic(n, w, U, return_cum=True)
+        assert cum.tobytes() == wcum.tobytes(), "cum_sum is not the sequential chain"
+        assert (got == want).all()
+    Us = rng.random(n)
+    got = B.resample_stratified_cpp(n, w, U=Us, ctx=ctx)
+    assert (got == oracle.resample_stratified(n, w, Us)).all()
+    Um = rng.random(n)
+    got = B.resample_multinomial_cpp(n, w, U=Um, ctx=ctx)
+    assert (got == oracle.resample_multinomial(n, w, Um)).all()
+
+
+@pytest.mark.parametrize("kind", ["range", "ties"])
+def test_bit_exact_adversarial(B, ctx, oracle, kind):
+    rng = np.random.default_rng(5)
+    for n in (3000, 50000):
+        w = _weights(rng, n, kind)
+        U = rng.random()
+        got, cum, stats = B.resample_systematic_cpp(n, w, U=U, ctx=ctx, return_cum=True, return_stats=True)
+        want, wcum = oracle.resample_systematic(n, w, U, return_cum=True)
+        assert cum.tobytes() == wcum.tobytes()
+        assert (got == want).all()
+
+
+def test_full_size_c5(B, ctx, oracle):
+    """BASELINE C5 size: N = 2^22, stratified.  Bit-exact against the oracle, plus size-independent
+    properties: sorted, in range, offspring counts within 1 of N*prob."""
+    n = 1 << 22
+    rng = np.random.default_rng(22)
+    w = np.exp(-0.5 * rng.standard_normal(n) ** 2)
+    Us = rng.random(n)
+    got, stats = B.resample_stratified_cpp(n, w, U=Us, ctx=ctx, return_stats=True)
+    assert (np.diff(got) >= 0).all() and got[0] >= 1 and got[-1] <= n
+    counts = np.bincount(got - 1, minlength=n)
+    assert np.all(np.abs(counts - n * w / w.sum()) < 2.0)
+    assert (got == oracle.resample_stratified(n, w, Us)).all()
+    # typical weights stay on the fast path: only the tail next to cum == 1.0 is literal
+    assert stats[2] < 4096, stats
+
+
+def test_n_differs_from_nw(B, ctx, oracle):
+    rng = np.random.default_rng(9)
+    w = rng.random(1000)
+    for n in (1, 10, 5000):
+        U = rng.random()
+        assert (B.resample_systematic_cpp(n, w, U=U, ctx=ctx) == oracle.resample_systematic(n, w, U)).all()
+
+
+def test_proportions(B, ctx):
+    # tests/testthat/test-resampling.R:29-47 (fewer repetitions: each call is a GPU round trip)
+    w = np.array([0.1, 0.2, 0.3, 0.2, 0.2])
+    rng = np.random.default_rng(1405)
+    reps = 400
+    for fn in (B.resample_systematic_cpp, B.resample_stratified_cpp, B.resample_multinomial_cpp):
+        counts = np.zeros(5)
+        for _ in range(reps):
+            U = rng.random() if fn is B.resample_systematic_cpp else rng.random(5)
+            counts += np.bincount(fn(5, w, U=U, ctx=ctx) - 1, minlength=5)
+        np.testing.assert_allclose(counts / (reps * 5), w, atol=0.05)
