@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/sec of the bootstrap-filter hot path on MI355X.
+
+A "step" is one full pass of the hot path over one batch: ONE bootstrap-filter run of BASELINE.json's
+config C2 (linear-Gaussian SSM, T = 1000 observations, N = 2^20 particles, SISR + systematic
+resampling, fp64, return_particles = FALSE) = N*T particle-steps.  Inputs (y, theta) are tiny and the
+particles never leave HBM; random draws come from the device generator.
+
+N GPUs: one process per GPU (torch.distributed, RCCL); the path shards at chain / replica granularity
+with no data-path collective, so every rank runs its own independent filter replica
+(same y, different generator stream) => weak scaling.  value = particle-steps of all ranks / max time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
+# algorithmic bytes per particle-step, d = 1 (SURVEY.md 8d / BASELINE.md 3): 32d + 36
+SWEEP_BYTES = 68.0
+SWEEP_READ_BYTES = 40.0
+# per-kernel algorithmic bytes per particle (this implementation's kernel split, d = 1)
+KERNEL_BYTES = {
+    "k_step<trans+weight>": 24.0,      # read x, write x', write lw
+    "k_normalize": 16.0,               # read lw, write w
+    "k_local<W>": 8.0,                 # read w
+    "k_local<P>": 8.0,                 # read w
+    "k_apply<systematic>": 24.0,       # read w, read x'[a], write x
+    "k_apply<stratified>": 24.0,
+}
+
+
+def simulate_lg(T, seed=1405, phi=0.8, sx=1.0, sy=1.0):
+    rng = np.random.default_rng(seed)
+    x, ys = rng.standard_normal(), np.empty(T)
+    for t in range(T):
+        x = phi * x + sx * rng.standard_normal()
+        ys[t] = x + sy * rng.standard_normal()
+    return ys
+
+
+def cpu_baseline(ys, theta, rank):
+    """The CPU oracle (restatement of the reference's R/Rcpp path, single thread) timed on a bounded
+    sample of the same workload.  Random draws are pre-generated and NOT timed (the reference pays for
+    rnorm inside its timed path, so this flatters the CPU)."""
+    from oracle import oracle as orc
+    orc.build()
+    Ns, Ts = 1 << 18, 200
+    rng = np.random.default_rng(7)
+    zi = rng.standard_normal(Ns)
+    zt = rng.standard_normal((Ts, Ns))
+    ur = rng.random(Ts)
+    t0 = time.perf_counter()
+    orc.pf_run("lg", theta, ys[:Ts], Ns, zi, zt, ur, resample_algorithm="SISR", resample_fn="systematic")
+    dt = time.perf_counter() - t0
+    return {"value": Ns * Ts / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": "oracle/bssm_oracle.c (C restatement of R/particle_filter_core.R + src/resampling.cpp), "
+                      "same model, N=2^18, T=200, SISR+systematic, draws pre-generated (not timed), %.1f s" % dt,
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=1 << 20)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--resample-fn", default="systematic")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import bayesssm_amd as b
+
+    N, T = args.particles, args.T
+    theta = (0.8, 1.0, 1.0)
+    ys = simulate_lg(T)
+    m = b.models.linear_gaussian()
+    ctx = b.Context(local_rank if world > 1 else 0, N, 1)
+
+    def run(stream):
+        return b.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn,
+                                  resample_algorithm="SISR", resample_fn=args.resample_fn, return_particles=False,
+                                  seed=1405, stream=stream, ctx=ctx, phi=theta[0], sigma_x=theta[1], sigma_y=theta[2])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for k in range(args.warmup):
+        run(1000 * rank + k)
+    barrier()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    last = None
+    for k in range(args.steps):
+        last = run(1000 * rank + 100 + k)
+        dev_ms += last["_extras"]["device_ms"]          # HIP events on the context's own stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    psteps = float(N) * T * args.steps * world
+    value = psteps / elapsed
+
+    out = None
+    if rank == 0:
+        per_run_ms = dev_ms / max(args.steps, 1)
+        sweep_gbs = SWEEP_BYTES * N * T / (per_run_ms * 1e-3) / 1e9
+        out = {
+            "metric": "particle-steps/sec (N x T), bootstrap filter", "value": value, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE C2: linear-Gaussian SSM, bootstrap filter, T=%d, N=%d, SISR + %s "
+                                   "resampling, return_particles=FALSE, device generator" % (T, N, args.resample_fn),
+                       "per_gpu": "one independent filter replica per GPU (no data-path collective)"},
+            "loglike_last_run": last["loglike"],
+            "sweep": {"device_ms_per_run": per_run_ms, "us_per_observation": 1e3 * per_run_ms / T,
+                      "algorithmic_bytes_per_particle_step": SWEEP_BYTES, "achieved_GBs": sweep_gbs,
+                      "frac_of_hbm_peak": sweep_gbs / HBM_PEAK_GBS,
+                      "read_only_frac": SWEEP_READ_BYTES * N * T / (per_run_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if not args.no_profile:
+            # one extra, un-timed pass with HIP events around every launch: per-kernel-class durations
+            ctx.set_profile(True)
+            run(999999)
+            prof = ctx.get_profile()
+            ctx.set_profile(False)
+            tot = sum(v["ms"] for v in prof.values())
+            kern = {k: {"avg_us": 1e3 * v["ms"] / max(v["launches"], 1), "launches": v["launches"],
+                        "share": v["ms"] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+            out["kernels"] = kern
+            dom = next(iter(kern))
+            nbytes = KERNEL_BYTES.get(dom, 0.0) * N
+            ach = nbytes / (kern[dom]["avg_us"] * 1e-6) / 1e9 if nbytes else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": kern[dom]["avg_us"]}
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": "whole sweep", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ys, theta, rank)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

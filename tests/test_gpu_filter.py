@@ -89,7 +89,7 @@ def test_resampler_in_situ_bit_exact(B, ctx, oracle):
     d = _draws(rng, oracle, "BPF", T, N, "systematic")
     m = B.models.linear_gaussian()
     res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm="SIS",
-                             draws=d, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
+                             resample_fn="systematic", draws=d, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
     for i in range(1, T + 1):
         w = res["weights_history"][i]
         U = rng.random()
