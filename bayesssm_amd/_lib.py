@@ -38,7 +38,7 @@ class PfConfig(C.Structure):
 class PfResult(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in (
         "state_est", "ess", "loglike_history", "loglike", "early_return_step", "n_res_calls", "resampled",
-        "ancestors", "particles_history", "weights_history", "device_ms")]
+        "ancestors", "particles_history", "weights_history", "device_ms", "scan_stats")]
 
 
 class PmmhConfig(C.Structure):

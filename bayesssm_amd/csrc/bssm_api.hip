@@ -43,6 +43,7 @@ struct bssm_ctx {
     // scan workspace
     double *pm = nullptr, *ps = nullptr, *bsum = nullptr, *bsq = nullptr, *ain_w = nullptr, *ain_p = nullptr;
     BlockRec* brec = nullptr;
+    SideList* side = nullptr;
     uint64_t* cin = nullptr;
     DevState* st = nullptr;
     // growable buffers
@@ -118,6 +119,7 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
     A((void**)&c->pm, MAXB * 8); A((void**)&c->ps, MAXB * 8); A((void**)&c->bsum, MAXB * 8); A((void**)&c->bsq, MAXB * 8);
     A((void**)&c->ain_w, MAXB * 8); A((void**)&c->ain_p, MAXB * 8);
     A((void**)&c->brec, MAXB * sizeof(BlockRec)); A((void**)&c->cin, MAXB * 8);
+    A((void**)&c->side, (size_t)B * sizeof(SideList));
     A((void**)&c->st, sizeof(DevState));
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -138,7 +140,7 @@ extern "C" void bssm_ctx_destroy(bssm_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->x0, c->x1, c->lw, c->w, c->auxlw, c->auxg, c->cum, c->pm, c->ps, c->bsum, c->bsq,
-                    c->ain_w, c->ain_p, c->brec, c->cin, c->st};
+                    c->ain_w, c->ain_p, c->brec, c->side, c->cin, c->st};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->pool) if (kv.second.first) (void)hipFree(kv.second.first);
     for (auto ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -157,6 +159,11 @@ extern "C" int bssm_ctx_synchronize(bssm_ctx* c)
 }
 
 extern "C" void* bssm_ctx_stream(bssm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// Development aid (tools/ only, not part of the ABI in include/): scan kernels return after stage N.
+static int g_debug_stop = 0;
+extern "C" void bssm_debug_set_stop(int stage) { g_debug_stop = stage; }
+__global__ void k_set_debug(DevState* st, int v) { st->debug_stop = v; }
 
 extern "C" int bssm_ctx_set_profile(bssm_ctx* c, int enable)
 {
@@ -218,6 +225,9 @@ static PhiloxKey make_key(unsigned long long seed, unsigned long long stream)
 // ---- the exact resampling pipeline on weights already in HBM ---------------------
 // resample_*_cpp: total = sum(w); prob = w/total; cum = cumsum(prob); walk.   src/resampling.cpp:16-66
 struct ResampleLaunch {
+    // filter path: weights are produced from log-weights inside the first scan kernel
+    const double* d_lw = nullptr; int plan = PLAN_RESAMPLE_ONLY; int check_degenerate = 0;
+    int obs_i = 0; int resample_algorithm = 1; double threshold = 0; double* d_ess = nullptr; double* d_llh = nullptr; int* d_resampled = nullptr;
     const double* d_w; long long nw; int n; int kind;
     const double* d_u; long long u_stride; PhiloxKey key;
     int* d_anc; long long anc_stride; double* d_cum;
@@ -230,10 +240,17 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     const int B = (int)((r.nw + EB - 1) / EB);
     const int lim = rec_window(r.nw);
     const size_t shm = (size_t)B * sizeof(BlockRec);
-    LAUNCH(c, "k_local<W>", k_local<MODE_W>, B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->st);
-    LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NT, shm, r.d_w, r.nw, B, c->brec, c->cin, c->ain_w, c->ain_p, c->st);
-    LAUNCH(c, "k_local<P>", k_local<MODE_P>, B, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec, c->st);
-    LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NT, shm, r.d_w, r.nw, B, c->brec, c->cin, c->ain_w, c->ain_p, c->st);
+    FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.nb = B; f.bsq = c->bsq;
+    f.ain_out = c->ain_w; f.check_degenerate = r.check_degenerate;
+    PlanArgs pa; pa.plan = r.plan; pa.pm = c->pm; pa.ps = c->ps; pa.bsq = c->bsq; pa.nb = B; pa.N = r.nw; pa.obs_i = r.obs_i;
+    pa.resample_algorithm = r.resample_algorithm; pa.threshold = r.threshold; pa.ess_out = r.d_ess; pa.llh_out = r.d_llh;
+    pa.resampled_out = r.d_resampled;
+    PlanArgs pnone = pa; pnone.plan = PLAN_RESAMPLE_ONLY;
+    if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f);
+    else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f);
+    LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st, pa);
+    LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), B, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec, c->side, c->st, f);
+    LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st, pnone);
     ApplyArgs a;
     a.w = r.d_w; a.nw = r.nw; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = r.n;
     a.u_base = r.d_u; a.u_stride = r.u_stride; a.key = r.key;
@@ -263,6 +280,7 @@ static int resample_common_device(bssm_ctx* c, int kind, int n, const double* d_
 {
     const int B = (nw + EB - 1) / EB;
     LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
+    if (g_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, g_debug_stop);
     LAUNCH(c, "k_bsum", k_bsum, B, NT, 0, d_w, (long long)nw, c->bsum, c->st);
     LAUNCH(c, "k_plan<resample>", k_plan<PLAN_RESAMPLE_ONLY>, 1, NT, 0, (const double*)nullptr, (const double*)nullptr, 0,
            c->bsum, (const double*)nullptr, B, c->ain_w, c->st, (long long)nw, 0, 0, 0.0,
@@ -501,9 +519,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         }
         if (apf) {                                                                        // :140-175
             launch_step_model(c, cfg->model, false, 2, false, X0, N, B, par, yi, noise(0));
-            LAUNCH(c, "k_normalize", k_normalize, B, NT, 0, c->auxlw, c->w, N, c->pm, c->ps, B, c->bsum, c->bsq, 0, c->st);
-            LAUNCH(c, "k_plan<aux>", k_plan<PLAN_AUX>, 1, NT, 0, c->pm, c->ps, B, c->bsum, c->bsq, B, c->ain_w, c->st, N, i,
-                   cfg->resample_algorithm, threshold, (double*)d_ess, (double*)d_llh, (int*)nullptr);
+            r.d_lw = c->auxlw; r.plan = PLAN_AUX; r.check_degenerate = 0; r.obs_i = i;
             r.xsrc = X0; r.xdst = X1; r.auxsrc = c->auxlw; r.auxdst = c->auxg; r.se_part = nullptr;
             launch_scan_and_apply(c, r);
             std::swap(X0, X1);
@@ -515,14 +531,12 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
             if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NT, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
             else LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NT, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
         }
-        LAUNCH(c, "k_normalize", k_normalize, B, NT, 0, c->lw, c->w, N, c->pm, c->ps, B, c->bsum, c->bsq, 1, c->st);       // :204-207
-        LAUNCH(c, "k_plan<pf>", k_plan<PLAN_PF>, 1, NT, 0, c->pm, c->ps, B, c->bsum, c->bsq, B, c->ain_w, c->st, N, i,
-               cfg->resample_algorithm, threshold, (double*)d_ess, (double*)d_llh, (int*)d_resampled);                     // :208-218
         double* se_row = separt + (size_t)i * B * dim;
-        if (cfg->resample_algorithm != BSSM_SIS) {                                                                          // :220-224
-            r.xsrc = X0; r.xdst = X1; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = se_row;
-            launch_scan_and_apply(c, r);
-        }
+        // normalise (:204-207) + loglik/ESS/decision (:208-218) + resample (:220-224), fused into the scan kernels
+        r.d_lw = c->lw; r.plan = PLAN_PF; r.check_degenerate = 1; r.obs_i = i; r.resample_algorithm = cfg->resample_algorithm;
+        r.threshold = threshold; r.d_ess = (double*)d_ess; r.d_llh = (double*)d_llh; r.d_resampled = (int*)d_resampled;
+        r.xsrc = X0; r.xdst = X1; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = se_row;
+        launch_scan_and_apply(c, r);
         if (cfg->resample_algorithm != BSSM_SISR)
             LAUNCH(c, "k_carry", k_carry, B, NT, 0, X0, X1, c->w, N, dim, se_row, c->st);
         std::swap(X0, X1);
@@ -548,6 +562,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     *res->loglike = h.loglike;
     if (res->early_return_step) *res->early_return_step = h.dead;
     if (res->n_res_calls) *res->n_res_calls = h.res_calls;
+    if (res->scan_stats) { res->scan_stats[0] = h.stat_hard_blocks; res->scan_stats[1] = h.stat_serial_walks; res->scan_stats[2] = h.stat_literal_terms; }
     if (h.dead) {   // the reference returns at once: later rows keep their initial values (:90-97)
         for (int i = h.dead; i <= T; i++) { res->ess[i] = 0.0; for (int d = 0; d < dim; d++) res->state_est[(size_t)i * dim + d] = 0.0; }
         for (int i = h.dead; i < T; i++) res->loglike_history[i] = 0.0;
@@ -629,7 +644,7 @@ extern "C" int bssm_pmmh_chain(bssm_ctx* c, const bssm_pmmh_config* cfg, bssm_pm
     pf.n_theta = p; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
     pf.seed = cfg->seed;
     bssm_pf_result pr; memset(&pr, 0, sizeof(pr));
-    pr.ess = ess.data(); pr.loglike_history = llh.data(); pr.loglike = &ll; pr.early_return_step = &ers; pr.n_res_calls = &nres; pr.device_ms = &ms;
+    pr.scan_stats = nullptr; pr.ess = ess.data(); pr.loglike_history = llh.data(); pr.loglike = &ll; pr.early_return_step = &ers; pr.n_res_calls = &nres; pr.device_ms = &ms;
     auto run_pf = [&](const std::vector<double>& th, std::vector<double>& se, unsigned iter) -> int {
         pf.theta = th.data(); pr.state_est = se.data();
         pf.stream = ((unsigned long long)cfg->chain_index << 32) | iter;

@@ -41,7 +41,12 @@ constexpr uint32_t FLAG_NEGATIVE = 1u, FLAG_ZERO_SUM = 2u, FLAG_NONFINITE = 4u;
 
 #define BSSM_LN_SQRT_2PI 0.918938533204672741780329736406
 
-struct BlockRec { Rec prefix; int32_t tail_from; int32_t pad; };   // 64 bytes
+struct BlockRec { Rec prefix; int32_t tail_from; int32_t nside; };   // 64 bytes
+// Blocks with several boundaries publish them, in lane order, next to the block record: the resolver
+// steps through  prefix, e[0].leaf, e[0].post, e[1].leaf, ...  with the exact state.
+constexpr int MAXBND = 64;       // boundaries handled per block before the literal fallback
+struct SideEntry { Rec leaf; int64_t d0, d1; uint64_t post_base; int32_t lo, hi; int32_t lane; int32_t pad; double terms[EL]; };  // 160 bytes
+struct SideList { SideEntry e[MAXBND]; };
 
 // Per-run scalars living in HBM; written by single-workgroup kernels, read by all.
 struct DevState {
@@ -54,7 +59,7 @@ struct DevState {
     uint32_t flags;               // FLAG_*
     int32_t res_calls;            // resample calls made so far
     int32_t cur_call;             // index of the resample call in flight
-    int32_t pad0;
+    int32_t debug_stop;           // dev tool: kernels return after stage N (0 = run everything)
     long long stat_hard_blocks, stat_serial_walks, stat_literal_terms;
 };
 
@@ -90,6 +95,30 @@ __device__ __forceinline__ double block_max(double v, double* sh4)
     __syncthreads();
     return fmax(fmax(sh4[0], sh4[1]), fmax(sh4[2], sh4[3]));
 }
+template <int NW>
+__device__ __forceinline__ double block_sum_n(double v, double* sh)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) s += sh[i];
+    return s;
+}
+template <int NW>
+__device__ __forceinline__ double block_max_n(double v, double* sh)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double m = sh[0];
+#pragma unroll
+    for (int i = 1; i < NW; i++) m = fmax(m, sh[i]);
+    return m;
+}
 // exclusive prefix of x over the block (re-associated: only an approximation
 // of the sequential prefix is needed here)
 __device__ __forceinline__ double block_excl_scan(double x, double* sh4)
@@ -120,17 +149,18 @@ __device__ __forceinline__ void lse_combine(double& m, double& s, double mb, dou
 
 // Reduce the per-block (max, sumexp) partials to the global pair; every
 // thread of every calling block gets the same value (same order everywhere).
-__device__ void reduce_lse_partials(const double* pm, const double* ps, int nb, double* sh4, double& M, double& S)
+template <int NW = NT / 64>
+__device__ void reduce_lse_partials(const double* pm, const double* ps, int nb, double* sh, double& M, double& S)
 {
     double m = -INFINITY;
-    for (int i = threadIdx.x; i < nb; i += NT) m = fmax(m, pm[i]);
-    M = block_max(m, sh4);
+    for (int i = threadIdx.x; i < nb; i += NW * 64) m = fmax(m, pm[i]);
+    M = block_max_n<NW>(m, sh);
     double s = 0.0;
-    for (int i = threadIdx.x; i < nb; i += NT) {
+    for (int i = threadIdx.x; i < nb; i += NW * 64) {
         const double mb = pm[i];
         if (mb > -INFINITY) s += ps[i] * exp(mb - M);
     }
-    S = block_sum(s, sh4);
+    S = block_sum_n<NW>(s, sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -375,19 +405,109 @@ __global__ __launch_bounds__(NT) void k_plan(const double* __restrict__ pm, cons
 }
 
 // ---------------------------------------------------------------------------
-// exact sequential scan: shared pieces
+// exact sequential scan (seqsum.h) -- device orchestration
+//
+// Almost every thread-chunk (8 terms) and every block of a real weight vector
+// is PURE: the running sum stays inside one binade, so its action on the state
+// is "add d0 ulps if the incoming low bit is 0, d1 if it is 1".  PURE maps
+// compose with two integer adds, so they are scanned with wave shuffles.  The
+// few lanes that are not PURE (a binade crossing, the exact-zero head, the
+// neighbourhood of cum == 1.0) are BOUNDARIES: they cut the scan into segments
+// and are stepped through one after the other, by one lane, with the exact
+// state.  Afterwards every PURE lane checks that its own exact incoming state
+// lies inside the window its record was built for (|in - hypothesis| <= lim);
+// one failed check anywhere discards the result and the block is re-run
+// literally, in order -- correctness never depends on the approximation.
 // ---------------------------------------------------------------------------
-struct ScanSmem {
-    Rec a[NT];
-    Rec b[NT];
-    Rec orig[NT];
-    uint64_t tin[NT];
-    double sh4[4];
-    int tail;
+struct Pure { int64_t d0, d1; };
+
+__device__ __forceinline__ Pure pure_compose(const Pure& f, const Pure& g)
+{
+    Pure c;
+    c.d0 = f.d0 + ((f.d0 & 1) ? g.d1 : g.d0);
+    c.d1 = f.d1 + (((f.d1 + 1) & 1) ? g.d1 : g.d0);
+    return c;
+}
+__device__ __forceinline__ uint64_t pure_step(const Pure& f, uint64_t in) { return in + (uint64_t)((in & 1) ? f.d1 : f.d0); }
+
+__device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off)
+{
+    int lo = (int)(uint32_t)(uint64_t)v, hi = (int)(uint32_t)((uint64_t)v >> 32);
+    lo = __shfl_up(lo, off, 64); hi = __shfl_up(hi, off, 64);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+struct SegSmem {
+    Pure wagg[16]; int wflag[16]; int wnb[16];
+    Pure bnd_excl[MAXBND]; Rec bnd_rec[MAXBND]; int bnd_lane[MAXBND]; uint64_t bnd_ent[MAXBND];
+    uint64_t seg_start[MAXBND + 1];
+    uint64_t lane_exit[4];       // exit state of the last lane of each wave (only [3] is used)
+    long long red_min[4][2], red_max[4][2];
+    uint64_t seg1_base;
+    uint64_t segbase[MAXBND + 1]; int smin[MAXBND + 1]; int smax[MAXBND + 1];
+    int nb; int fail; int first_bnd; int first_kind;
+    double sh4[16];
+    double bcast;
 };
 
+// Segmented exclusive scan over the NT lanes of a block.  `isb`: this lane is a
+// boundary (contributes the identity, ends the segment).  Returns the
+// composite of the PURE lanes between the previous boundary and this lane,
+// the lane's segment index (= number of boundaries before it), and leaves the
+// boundary count in sm.nb.
+template <int NW>
+__device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, bool isb, int& seg, int& nb_total, Pure& block_incl_last_seg)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned long long bal = __ballot(isb);
+    const unsigned long long below = bal & ((1ull << lane) - 1ull);
+    // head flag: the previous lane is a boundary (lane 0 of a wave: decided across waves)
+    bool f = (lane > 0) && ((bal >> (lane - 1)) & 1ull);
+    Pure v; v.d0 = isb ? 0 : leaf.d0; v.d1 = isb ? 0 : leaf.d1;
+    int fi = f ? 1 : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        Pure pv; pv.d0 = shfl_up_i64(v.d0, off); pv.d1 = shfl_up_i64(v.d1, off);
+        const int pf = __shfl_up(fi, off, 64);
+        if (lane >= off && !fi) { v = pure_compose(pv, v); fi = pf; }
+    }
+    // v = composite from the segment head (or the wave start) up to and including this lane
+    if (lane == 63) {
+        sm.wagg[wave] = v; sm.wflag[wave] = (bal != 0ull) ? 1 : 0;   // a boundary anywhere in the wave cuts the carry
+        sm.wnb[wave] = __popcll(bal);
+    }
+    // NOTE: if the wave's LAST lane is a boundary the carry into the next wave is the identity
+    const bool last_is_b = (bal >> 63) & 1ull;
+    if (lane == 63 && last_is_b) { sm.wagg[wave].d0 = 0; sm.wagg[wave].d1 = 0; }
+    __syncthreads();
+    Pure carry; carry.d0 = 0; carry.d1 = 0;
+    int segbase = 0;
+    for (int w = 0; w < wave; w++) {
+        if (sm.wflag[w]) carry = sm.wagg[w]; else carry = pure_compose(carry, sm.wagg[w]);
+        segbase += sm.wnb[w];
+    }
+    nb_total = 0;
+    for (int w = 0; w < NW; w++) nb_total += sm.wnb[w];
+    {   // composite of the block's LAST segment, through the last lane
+        Pure c; c.d0 = 0; c.d1 = 0;
+        for (int w = 0; w < NW; w++) { if (sm.wflag[w]) c = sm.wagg[w]; else c = pure_compose(c, sm.wagg[w]); }
+        block_incl_last_seg = c;
+    }
+    // inclusive value with the carry from earlier waves (lanes before the wave's first boundary)
+    // lanes at or before the first boundary of the wave (inclusive of that boundary lane) still belong to the carried segment
+    const bool carried = (below == 0ull);
+    Pure inc = carried ? pure_compose(carry, v) : v;
+    // exclusive = inclusive of the previous lane, unless the previous lane is a boundary
+    Pure exc; exc.d0 = shfl_up_i64(inc.d0, 1); exc.d1 = shfl_up_i64(inc.d1, 1);
+    if (lane == 0) exc = carry;
+    if (lane > 0 && ((bal >> (lane - 1)) & 1ull)) { exc.d0 = 0; exc.d1 = 0; }
+    // lane 0 of a wave whose predecessor (lane 63 of the previous wave) is a boundary: carry is already the identity
+    seg = segbase + __popcll(below);
+    return exc;
+}
+
 template <int MODE>
-__device__ __forceinline__ void load_terms(const double* __restrict__ w, long long nw, double total, long long j0, double v[EL])
+__device__ __forceinline__ void load_terms(const double* __restrict__ w, long long nw, double total, long long j0, double (&v)[EL])
 {
     if (j0 + EL <= nw) {
         const double2* p = reinterpret_cast<const double2*>(w + j0);
@@ -420,164 +540,502 @@ __device__ uint64_t literal_run(const double* __restrict__ w, long long nw, doub
     return d2b(c);
 }
 
-// Hillis-Steele inclusive scan of the 256 thread records in LDS.
-__device__ __forceinline__ void scan_records(ScanSmem& sm, const Rec& mine, Rec& inc, Rec& exc)
-{
-    const int t = threadIdx.x;
-    sm.orig[t] = mine;
-    sm.a[t] = mine;
-    __syncthreads();
-    Rec* src = sm.a;
-    Rec* dst = sm.b;
-    for (int off = 1; off < NT; off <<= 1) {
-        Rec r = src[t];
-        if (t >= off) r = rec_compose(src[t - off], r);
-        dst[t] = r;
-        __syncthreads();
-        Rec* tmp = src; src = dst; dst = tmp;
-    }
-    inc = src[t];
-    if (t > 0) exc = src[t - 1]; else exc = rec_identity(0);
-}
+// Everything a block knows before the exact incoming state is available.
+struct BlockScan {
+    Rec leaf;          // this lane's record (general form)
+    Pure pleaf;        // PURE form (valid when !isb)
+    Pure exc;          // composite of the PURE lanes between the previous boundary and this lane
+    Pure last_seg;     // composite of the block's last segment through the last lane
+    bool isb;
+    int seg, nb;
+};
 
-// ---------------------------------------------------------------------------
-// k_local: block record = composite of threads [0, tail_from)
-// ---------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long long nw, const double* __restrict__ ain,
-                                              int lim, BlockRec* __restrict__ brec, DevState* st)
+__device__ __forceinline__ void block_scan(SegSmem& sm, const double (&v)[EL], double a_in, int lim, BlockScan& bs)
 {
-    if (st->dead || !st->do_resample || st->flags) return;
-    __shared__ ScanSmem sm;
-    const int t = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * EB;
-    const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
-    double v[EL];
-    load_terms<MODE>(w, nw, total, b0 + (long long)t * EL, v);
     double ts = 0.0;
 #pragma unroll
     for (int k = 0; k < EL; k++) ts += v[k];
-    const double a_in = ain[blockIdx.x];
     const double h = a_in + block_excl_scan(ts, sm.sh4);
-    const Rec mine = chunk_record(v, EL, 1, h, lim);
-    Rec inc, exc;
-    if (t == 0) sm.tail = NT;
-    scan_records(sm, mine, inc, exc);
-    if (inc.kind == REC_HARD) atomicMin(&sm.tail, t);
+    bs.leaf = chunk_record_fixed<EL>(v, h, lim);
+    bs.isb = bs.leaf.kind != REC_PURE;
+    bs.pleaf.d0 = (int64_t)(bs.leaf.o[0] - bs.leaf.base);
+    bs.pleaf.d1 = (int64_t)(bs.leaf.o[1] - (bs.leaf.base + 1));
+    bs.exc = seg_excl_scan<NT / 64>(sm, bs.pleaf, bs.isb, bs.seg, bs.nb, bs.last_seg);
+    // publish the boundaries in lane order
+    if (bs.isb && bs.seg < MAXBND) {
+        Rec& d = sm.bnd_rec[bs.seg];
+        d.base = bs.leaf.base; d.o[0] = bs.leaf.o[0]; d.o[1] = bs.leaf.o[1]; d.o[2] = bs.leaf.o[2]; d.o[3] = bs.leaf.o[3];
+        d.kind = bs.leaf.kind; d.lo = bs.leaf.lo; d.hi = bs.leaf.hi; d.pad = 0;
+        sm.bnd_excl[bs.seg].d0 = bs.exc.d0; sm.bnd_excl[bs.seg].d1 = bs.exc.d1; sm.bnd_lane[bs.seg] = threadIdx.x;
+    }
+}
+
+// With the exact incoming state of the block: exact incoming state of every lane.
+// Returns false (block-uniform) if the records did not cover the exact states;
+// the caller then falls back to block_literal().
+template <int MODE>
+__device__ __forceinline__ bool block_resolve(SegSmem& sm, const BlockScan& bs, uint64_t cin, int lim,
+                                              const double* __restrict__ w, long long nw, double total, long long b0,
+                                              uint64_t& ent)
+{
+    const int t = threadIdx.x;
+    if (t == 0) sm.fail = (bs.nb > MAXBND) ? 1 : 0;
     __syncthreads();
-    const int tail = sm.tail;
-    if (tail < NT && a_in == 0.0) {
-        // incoming state is exactly +0: walk the thread records with the exact state now
+    if (t == 0 && bs.nb <= MAXBND) {
+        uint64_t s = cin;
+        sm.seg_start[0] = s;
+        for (int k = 0; k < bs.nb; k++) {
+            const uint64_t e = pure_step(sm.bnd_excl[k], s);
+            sm.bnd_ent[k] = e;
+            bool ok = true;
+            uint64_t o = rec_step(sm.bnd_rec[k], e, ok);
+            if (!ok) { const long long j0 = b0 + (long long)sm.bnd_lane[k] * EL; o = literal_run<MODE>(w, nw, total, j0, j0 + EL, e); }
+            s = o;
+            sm.seg_start[k + 1] = s;
+        }
+    }
+    __syncthreads();
+    if (sm.fail) return false;
+    bool ok = true;
+    if (bs.isb) ent = sm.bnd_ent[bs.seg];
+    else {
+        ent = pure_step(bs.exc, sm.seg_start[bs.seg]);
+        const int64_t diff = (int64_t)(ent - bs.leaf.base);
+        ok = (diff >= -(int64_t)lim) && (diff <= (int64_t)lim);
+    }
+    if (!ok) sm.fail = 1;
+    __syncthreads();
+    return sm.fail == 0;
+}
+
+// Literal fallback: thread 0 runs the whole block in order and records each lane's incoming state.
+template <int MODE>
+__device__ __forceinline__ void block_literal(uint64_t* tin /* LDS [NT] */, uint64_t cin, const double* __restrict__ w,
+                                              long long nw, double total, long long b0, DevState* st)
+{
+    if (threadIdx.x == 0) {
+        double c = b2d(cin);
+        for (int tt = 0; tt < NT; tt++) {
+            tin[tt] = d2b(c);
+            for (int k = 0; k < EL; k++) c = c + term_at<MODE>(w, nw, total, b0 + (long long)tt * EL + k);
+        }
+        atomicAdd((unsigned long long*)&st->stat_serial_walks, 1ull);
+        atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)EB);
+    }
+    __syncthreads();
+}
+
+// block-wide min and max of two int64 pairs (segments 0 and 1), lanes opt in per segment
+__device__ __forceinline__ void block_minmax2(SegSmem& sm, long long mn[2], long long mx[2])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            int lo = (int)(uint32_t)(uint64_t)mn[s], hi = (int)(uint32_t)((uint64_t)mn[s] >> 32);
+            lo = __shfl_down(lo, off, 64); hi = __shfl_down(hi, off, 64);
+            const long long o = (long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+            mn[s] = (o < mn[s]) ? o : mn[s];
+            lo = (int)(uint32_t)(uint64_t)mx[s]; hi = (int)(uint32_t)((uint64_t)mx[s] >> 32);
+            lo = __shfl_down(lo, off, 64); hi = __shfl_down(hi, off, 64);
+            const long long p = (long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+            mx[s] = (p > mx[s]) ? p : mx[s];
+        }
+    }
+    __syncthreads();
+    if (lane == 0) { sm.red_min[wave][0] = mn[0]; sm.red_min[wave][1] = mn[1]; sm.red_max[wave][0] = mx[0]; sm.red_max[wave][1] = mx[1]; }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        long long a = sm.red_min[0][s], b = sm.red_max[0][s];
+        for (int wv = 1; wv < 4; wv++) { a = sm.red_min[wv][s] < a ? sm.red_min[wv][s] : a; b = sm.red_max[wv][s] > b ? sm.red_max[wv][s] : b; }
+        mn[s] = a; mx[s] = b;
+    }
+}
+
+__device__ __forceinline__ Rec pure_to_rec(const Pure& p, uint64_t base, long long lo, long long hi)
+{
+    Rec r; r.pad = 0; r.base = base & ~3ull; r.kind = REC_PURE;
+    r.o[0] = r.base + (uint64_t)p.d0; r.o[1] = r.base + 1 + (uint64_t)p.d1;
+    r.o[2] = r.base + 2 + (uint64_t)p.d0; r.o[3] = r.base + 3 + (uint64_t)p.d1;
+    const long long L = -(1ll << 30), H = (1ll << 30);
+    r.lo = (int32_t)(lo < L ? L : (lo > H ? H : lo));
+    r.hi = (int32_t)(hi < L ? L : (hi > H ? H : hi));
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// k_local: the block's record for the grid-level resolve.
+//   no boundary            -> PURE record (d0,d1) + validity window
+//   one X1 boundary        -> X1 record  (pre . crossing . post)
+//   incoming state is +0   -> the block resolves itself now: ABS record
+//   otherwise              -> prefix record up to the first boundary + tail_from
+// ---------------------------------------------------------------------------
+// FROM_LW (filter path, MODE_W): the kernel also IS the normalisation step -- it turns log-weights
+// into weights  w = exp(lw - max) / sum  (R/particle_filter_core.R:205-207), writes them, and derives
+// the approximate block prefixes from the log-sum-exp partials instead of a separate pass.
+struct FromLw {
+    const double* lw; double* w_out; const double* pm; const double* ps; int nb;
+    double* bsq; double* ain_out; int check_degenerate;
+};
+
+template <int MODE, bool FROM_LW>
+__global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long long nw, const double* __restrict__ ain,
+                                              int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
+                                              FromLw f)
+{
+    if (st->dead || st->flags) return;
+    if (!FROM_LW && !st->do_resample) return;
+    __shared__ SegSmem sm;
+    __shared__ uint64_t tin[NT];
+    const int t = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * EB;
+    const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
+    const int dbg = st->debug_stop;
+    double v[EL];
+    double a_in;
+    if (FROM_LW) {
+        double M, S;
+        reduce_lse_partials(f.pm, f.ps, f.nb, sm.sh4, M, S);
+        if (f.check_degenerate && M < -1e8) return;          // degenerate: the resolve/plan step marks the run dead (:189)
+        // approximate block sums of w from the partials: sum_b = ps[b] exp(pm[b] - M) / S
+        double loc[MAXB / NT];
+        double ts0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < MAXB / NT; k++) {
+            const int i = t * (MAXB / NT) + k;
+            double x = 0.0;
+            if (i < f.nb) { const double mb = f.pm[i]; x = (mb > -INFINITY) ? f.ps[i] * exp(mb - M) / S : 0.0; }
+            loc[k] = x; ts0 += x;
+        }
+        double pre = block_excl_scan(ts0, sm.sh4);
+#pragma unroll
+        for (int k = 0; k < MAXB / NT; k++) {
+            const int i = t * (MAXB / NT) + k;
+            if (i == (int)blockIdx.x) sm.bcast = pre;
+            if (blockIdx.x == 0 && i < f.nb) f.ain_out[i] = pre;
+            pre += loc[k];
+        }
+        __syncthreads();
+        a_in = sm.bcast;
+        const long long j0 = b0 + (long long)t * EL;
+        double s2 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < EL; k++) {
+            const double l = (j0 + k < nw) ? f.lw[j0 + k] : -INFINITY;
+            const double x = (j0 + k < nw) ? exp(l - M) / S : 0.0;
+            v[k] = x; s1 += x; s2 += x * x;
+            if (j0 + k < nw) f.w_out[j0 + k] = x;
+        }
+        s2 = block_sum(s2, sm.sh4);
+        s1 = block_sum(s1, sm.sh4);
         if (t == 0) {
-            uint64_t s = 0;
-            long long lit = 0;
-            for (int tt = 0; tt < NT; tt++) {
-                bool ok = true;
-                uint64_t o = rec_step(sm.orig[tt], s, ok);
-                if (!ok) { o = literal_run<MODE>(w, nw, total, b0 + (long long)tt * EL, b0 + (long long)(tt + 1) * EL, s); lit += EL; }
-                s = o;
-            }
-            BlockRec br; br.prefix = rec_abs(s); br.tail_from = NT; br.pad = 0;
+            f.bsq[blockIdx.x] = s2;
+            if (!isfinite(s1)) atomicOr(&st->flags, FLAG_NONFINITE);   // NaN/Inf log-weights: the scan stands down
+        }
+        if (!isfinite(s1)) return;
+    } else {
+        load_terms<MODE>(w, nw, total, b0 + (long long)t * EL, v);
+        a_in = ain[blockIdx.x];
+    }
+    if (dbg == 1) { if (v[0] + v[7] == -1.0) tin[t] = 1; return; }
+    BlockScan bs;
+    block_scan<MODE>(sm, v, a_in, lim, bs);
+    __syncthreads();
+    if (dbg == 2) { if (bs.exc.d0 == -12345) tin[t] = 1; return; }
+    if (dbg == 3 && a_in == 0.0) return;
+    const uint64_t hb0 = d2b(a_in) & ~3ull;
+    if (a_in == 0.0) {
+        // exact incoming state (+0): resolve now and publish the exact outgoing state
+        uint64_t ent;
+        bool good = block_resolve<MODE>(sm, bs, 0ull, lim, w, nw, total, b0, ent);
+        if (!good) { block_literal<MODE>(tin, 0ull, w, nw, total, b0, st); ent = tin[t]; }
+        if (t == NT - 1) {
+            double c = b2d(ent);
+#pragma unroll
+            for (int k = 0; k < EL; k++) c = c + v[k];
+            BlockRec br; br.prefix = rec_abs(d2b(c)); br.tail_from = NT; br.nside = 0;
             brec[blockIdx.x] = br;
-            atomicAdd((unsigned long long*)&st->stat_serial_walks, 1ull);
-            atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
         }
         return;
     }
-    if (tail == NT) {
-        if (t == NT - 1) { BlockRec br; br.prefix = inc; br.tail_from = NT; br.pad = 0; brec[blockIdx.x] = br; }
-    } else if (tail == 0) {
-        if (t == 0) {
-            BlockRec br; br.prefix = rec_identity(d2b(a_in)); br.tail_from = 0; br.pad = 0; brec[blockIdx.x] = br;
+    // validity windows of segment 0 (lanes before the first boundary) and of the last segment when nb == 1
+    if (t == 0) { sm.first_bnd = NT; sm.first_kind = REC_PURE; }
+    __syncthreads();
+    if (bs.isb && bs.seg == 0) { sm.first_bnd = t; sm.first_kind = bs.leaf.kind; }
+    __syncthreads();
+    const int fb = sm.first_bnd;
+    if (bs.nb >= 1 && t == fb + 1) sm.seg1_base = bs.leaf.base;
+    __syncthreads();
+    long long mn[2] = {(1ll << 40), (1ll << 40)}, mx[2] = {-(1ll << 40), -(1ll << 40)};
+    if (!bs.isb && bs.seg <= 1) {
+        const uint64_t sb = (bs.seg == 0) ? hb0 : (sm.seg1_base & ~3ull);
+        const long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
+        const long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
+        const long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
+        if (bs.seg == 0) { mn[0] = lo_; mx[0] = hi_; } else { mn[1] = lo_; mx[1] = hi_; }   // no runtime index: keeps mn/mx in registers
+    }
+    block_minmax2(sm, mn, mx);
+    // segment-0 prefix record: lanes [0, fb)
+    if (bs.nb == 0) {
+        if (t == NT - 1) {
+            BlockRec br; br.prefix = pure_to_rec(bs.last_seg, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
+            br.tail_from = NT; br.nside = 0; brec[blockIdx.x] = br;
+        }
+        return;
+    }
+    bool done1 = false;
+    if (t == fb) {
+        // bs.exc of the first boundary lane = composite of segment 0
+        Rec pre = (fb == 0) ? rec_identity(hb0) : pure_to_rec(bs.exc, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
+        BlockRec br;
+        if (bs.nb == 1 && bs.leaf.kind == REC_X1) {
+            Rec r = rec_compose(pre, bs.leaf);
+            if (fb < NT - 1) {
+                const Rec post = pure_to_rec(bs.last_seg, sm.seg1_base, -(long long)lim - mn[1] + 4, (long long)lim - mx[1] - 4);
+                r = rec_compose(r, post);
+            }
+            if (r.kind != REC_HARD) { br.prefix = r; br.tail_from = NT; br.nside = 0; brec[blockIdx.x] = br; done1 = true; }
+        }
+        if (!done1) {
+            br.prefix = pre;
+            if (bs.nb <= MAXBND) { br.tail_from = NT; br.nside = bs.nb; }     // side list below
+            else { br.tail_from = fb; br.nside = 0; }                          // too many: literal tail
+            brec[blockIdx.x] = br;
             atomicAdd((unsigned long long*)&st->stat_hard_blocks, 1ull);
         }
-    } else if (t == tail - 1) {
-        BlockRec br; br.prefix = inc; br.tail_from = tail; br.pad = 0; brec[blockIdx.x] = br;
-        atomicAdd((unsigned long long*)&st->stat_hard_blocks, 1ull);
+        sm.fail = done1 ? 1 : 0;      // reuse as "record complete" flag for the block
+    }
+    __syncthreads();
+    if (sm.fail || bs.nb > MAXBND) return;
+    // ---- side list: every boundary leaf + the PURE segment after it, with that segment's window ----
+    for (int k = t; k <= MAXBND; k += NT) { sm.smin[k] = 0x7fffffff; sm.smax[k] = -0x7fffffff; }
+    // the first lane of a segment (the lane after boundary seg-1) publishes the segment's hypothesis base
+    if (!bs.isb && bs.seg >= 1 && t == sm.bnd_lane[bs.seg - 1] + 1) sm.segbase[bs.seg] = bs.leaf.base;
+    __syncthreads();
+    if (!bs.isb && bs.seg >= 1) {
+        const uint64_t sb = sm.segbase[bs.seg] & ~3ull;
+        long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
+        long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
+        long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
+        const long long C = (1ll << 30);
+        lo_ = lo_ < -C ? -C : (lo_ > C ? C : lo_); hi_ = hi_ < -C ? -C : (hi_ > C ? C : hi_);
+        atomicMin(&sm.smin[bs.seg], (int)lo_);
+        atomicMax(&sm.smax[bs.seg], (int)hi_);
+    }
+    __syncthreads();
+    if (bs.isb) {
+        const int k = bs.seg;
+        SideEntry& e = side[blockIdx.x].e[k];
+        e.leaf = bs.leaf;
+        const Pure post = (k + 1 < bs.nb) ? sm.bnd_excl[k + 1] : bs.last_seg;
+        e.d0 = post.d0; e.d1 = post.d1;
+        const bool has_post = (sm.smin[k + 1] != 0x7fffffff);
+        e.post_base = has_post ? (sm.segbase[k + 1] & ~3ull) : 0ull;
+        const long long lo = has_post ? (-(long long)lim - (long long)sm.smin[k + 1] + 4) : -(1ll << 30);
+        const long long hi = has_post ? ((long long)lim - (long long)sm.smax[k + 1] - 4) : (1ll << 30);
+        e.lo = (int32_t)(lo < -(1ll << 30) ? -(1ll << 30) : (lo > (1ll << 30) ? (1ll << 30) : lo));
+        e.hi = (int32_t)(hi < -(1ll << 30) ? -(1ll << 30) : (hi > (1ll << 30) ? (1ll << 30) : hi));
+        e.lane = t; e.pad = has_post ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < EL; q++) e.terms[q] = v[q];     // so the resolver can re-run this leaf without chasing w[]
     }
 }
 
 // ---------------------------------------------------------------------------
 // k_resolve (one workgroup): exact incoming state cin[b] of every block.
-// Blocks are taken in ~sqrt(B) groups: group records by composition, one
-// serial walk over the groups with the exact state, then every group walks
-// its own blocks.  Tails / window misses are re-run literally.
+// Same scheme one level up: each thread owns CB consecutive block records; a
+// run of PURE blocks is a PURE chunk, anything else is a boundary chunk.
 // ---------------------------------------------------------------------------
 template <int MODE>
-__device__ uint64_t block_out_exact(const BlockRec& br, const double* __restrict__ w, long long nw, double total,
-                                    long long b, uint64_t in, long long& lit)
+__device__ uint64_t block_out_exact(const BlockRec& br, const SideList* __restrict__ side, const double* __restrict__ w,
+                                    long long nw, double total, long long b, uint64_t in, long long& lit)
 {
     bool ok = true;
-    const uint64_t o = rec_step(br.prefix, in, ok);
+    uint64_t o = rec_step(br.prefix, in, ok);
     const long long e0 = b * EB, e1 = (e0 + EB < nw) ? e0 + EB : nw;
-    if (ok) {
-        if (br.tail_from >= NT) return o;
-        const long long j0 = e0 + (long long)br.tail_from * EL;
-        if (j0 >= e1) return o;
-        lit += e1 - j0;
-        return literal_run<MODE>(w, nw, total, j0, e1, o);
+    if (!ok) {                                   // the prefix record does not cover this state: whole block literally
+        lit += (e1 > e0) ? e1 - e0 : 0;
+        return literal_run<MODE>(w, nw, total, e0, e1, in);
     }
-    lit += (e1 > e0) ? e1 - e0 : 0;
-    return literal_run<MODE>(w, nw, total, e0, e1, in);
+    if (br.nside > 0) {
+        const SideEntry* se = side[b].e;
+        for (int k = 0; k < br.nside; k++) {
+            const SideEntry e = se[k];
+            bool ok2 = true;
+            uint64_t o2 = rec_step(e.leaf, o, ok2);
+            if (!ok2) {                          // HARD leaf (or window miss): its 8 terms literally
+                double c = b2d(o);
+#pragma unroll
+                for (int q = 0; q < EL; q++) c = c + e.terms[q];
+                o2 = d2b(c);
+                lit += EL;
+            }
+            o = o2;
+            if (e.pad) {                         // PURE segment after the boundary
+                const int64_t diff = (int64_t)(o - e.post_base);
+                if (diff < (int64_t)e.lo || diff > (int64_t)e.hi) {
+                    const long long j0 = e0 + (long long)(e.lane + 1) * EL;   // not covered: rest of the block literally
+                    if (j0 < e1) { lit += e1 - j0; o = literal_run<MODE>(w, nw, total, j0, e1, o); }
+                    return o;
+                }
+                Pure p; p.d0 = e.d0; p.d1 = e.d1;
+                o = pure_step(p, o);
+            }
+        }
+        return o;
+    }
+    if (br.tail_from >= NT) return o;
+    const long long j0 = e0 + (long long)br.tail_from * EL;
+    if (j0 >= e1) return o;
+    lit += e1 - j0;
+    return literal_run<MODE>(w, nw, total, j0, e1, o);
 }
 
+constexpr int NTR = 1024;        // threads of the single resolve workgroup (16 waves)
+constexpr int SIDE_CACHE = 12;   // side entries staged in LDS for the boundary walk
+
+// In the filter the MODE_W resolve also does the per-observation bookkeeping that needs every block's
+// partials: log-likelihood increment, ESS, resample decision (R/particle_filter_core.R:189-218).
+struct PlanArgs {
+    int plan;                 // PLAN_RESAMPLE_ONLY: nothing to do here
+    const double* pm; const double* ps; const double* bsq; int nb;
+    long long N; int obs_i; int resample_algorithm; double threshold;
+    double* ess_out; double* llh_out; int* resampled_out;
+};
+
 template <int MODE>
-__global__ __launch_bounds__(NT) void k_resolve(const double* __restrict__ w, long long nw, int B,
-                                                const BlockRec* __restrict__ brec, uint64_t* __restrict__ cin,
-                                                const double* __restrict__ ain_w, double* __restrict__ ain_p, DevState* st)
+__global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, long long nw, int B,
+                                                 const BlockRec* __restrict__ brec, const SideList* __restrict__ side,
+                                                 uint64_t* __restrict__ cin,
+                                                 const double* __restrict__ ain_w, double* __restrict__ ain_p, DevState* st,
+                                                 PlanArgs pa)
 {
-    if (st->dead || !st->do_resample || st->flags) return;
+    if (st->dead || st->flags) return;
     extern __shared__ __attribute__((aligned(16))) char smraw[];
     BlockRec* br = reinterpret_cast<BlockRec*>(smraw);
-    __shared__ Rec grec[MAXG];
-    __shared__ uint64_t gin[MAXG];
+    __shared__ SegSmem sm;
     __shared__ uint64_t final_state;
     const int t = threadIdx.x;
+    if (MODE == MODE_W && pa.plan != PLAN_RESAMPLE_ONLY) {
+        __shared__ int go;
+        if (pa.plan == PLAN_PF) {
+            double M, S;
+            reduce_lse_partials<NTR / 64>(pa.pm, pa.ps, pa.nb, sm.sh4, M, S);
+            double q = 0.0;
+            for (int i = t; i < pa.nb; i += NTR) q += pa.bsq[i];
+            if (M < -1e8) q = 0.0;
+            q = block_sum_n<NTR / 64>(q, sm.sh4);
+            if (t == 0) {
+                if (M < -1e8) {                  // all(log_weights < -1e8)  (:189-202)
+                    st->loglike = -INFINITY; pa.llh_out[pa.obs_i - 1] = -INFINITY; st->dead = pa.obs_i; st->do_resample = 0;
+                    go = 0;
+                } else {
+                    const double ll = st->loglike + (M + log(S) - log((double)pa.N));   // :208
+                    st->loglike = ll; pa.llh_out[pa.obs_i - 1] = ll;                     // :209
+                    const double ess = 1.0 / q;                                          // :211
+                    const int doit = (pa.resample_algorithm == 0) ? 0 : (pa.resample_algorithm == 1) ? 1 : (ess < pa.threshold);  // :214-218
+                    st->do_resample = doit;
+                    pa.ess_out[pa.obs_i] = doit ? (double)pa.N : ess;                    // :212,:223
+                    if (pa.resampled_out) pa.resampled_out[pa.obs_i - 1] = doit;
+                    st->ess = ess; st->lse_max = M; st->lse_sum = S;
+                    if (doit) { st->cur_call = st->res_calls; st->res_calls += 1; }
+                    go = doit;
+                }
+            }
+        } else if (t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; go = 1; }
+        __syncthreads();
+        if (!go) return;
+    } else {
+        if (!st->do_resample) return;
+    }
     {   // stage the block records in LDS (16-byte pieces)
         const uint4* src = reinterpret_cast<const uint4*>(brec);
         uint4* dst = reinterpret_cast<uint4*>(smraw);
         const int n16 = B * (int)(sizeof(BlockRec) / 16);
-        for (int i = t; i < n16; i += NT) dst[i] = src[i];
+        for (int i = t; i < n16; i += NTR) dst[i] = src[i];
     }
+    if (t == 0) sm.fail = 0;
     __syncthreads();
+    const int dbg = st->debug_stop;
+    if (dbg == 11) return;
     const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
-    int G = 1;
-    while (G * G < B) G++;
-    const int NG = (B + G - 1) / G;
-    if (t < NG) {
-        const int b0 = t * G, b1 = (b0 + G < B) ? b0 + G : B;
-        Rec r = (br[b0].tail_from < NT) ? rec_hard(0) : br[b0].prefix;
-        for (int b = b0 + 1; b < b1; b++) r = (br[b].tail_from < NT) ? rec_hard(0) : rec_compose(r, br[b].prefix);
-        grec[t] = r;
+    const int CB = (B + NTR - 1) / NTR;                // blocks per thread (1 or 2)
+    const int c0 = t * CB, c1 = (c0 + CB < B) ? c0 + CB : B;
+    // chunk record: PURE composite + validity window relative to the first block's base
+    bool isb = false;
+    Pure comp; comp.d0 = 0; comp.d1 = 0;
+    long long wlo = -(1ll << 40), whi = (1ll << 40);
+    uint64_t cbase = 0;
+    for (int b = c0; b < c1; b++) {
+        const BlockRec& r = br[b];
+        if (r.prefix.kind != REC_PURE || r.tail_from < NT || r.nside > 0) { isb = true; break; }
+        if (b == c0) cbase = r.prefix.base;
+        const long long m0 = (long long)(cbase + (uint64_t)comp.d0 - r.prefix.base);
+        const long long m1 = (long long)(cbase + 1 + (uint64_t)comp.d1 - r.prefix.base);
+        const long long mmin = m0 < m1 ? m0 : m1, mmax = m0 > m1 ? m0 : m1;
+        const long long lo = (long long)r.prefix.lo - mmin + 2, hi = (long long)r.prefix.hi - mmax - 2;
+        wlo = lo > wlo ? lo : wlo; whi = hi < whi ? hi : whi;
+        Pure p; p.d0 = (int64_t)(r.prefix.o[0] - r.prefix.base); p.d1 = (int64_t)(r.prefix.o[1] - (r.prefix.base + 1));
+        comp = pure_compose(comp, p);
     }
+    if (c0 >= B) { isb = false; comp.d0 = comp.d1 = 0; }    // padding lanes: identity
+    if (dbg == 12) { if (comp.d0 == -12345) cin[0] = 1; return; }
+    int seg, nb; Pure lastseg;
+    const Pure exc = seg_excl_scan<NTR / 64>(sm, comp, isb, seg, nb, lastseg);
+    if (isb && seg < MAXBND) { sm.bnd_excl[seg] = exc; sm.bnd_lane[seg] = t; }
     __syncthreads();
+    if (dbg == 13) { if (exc.d0 == -12345) cin[0] = 1; return; }
     long long lit = 0;
     if (t == 0) {
-        uint64_t s = 0;
-        for (int g = 0; g < NG; g++) {
-            gin[g] = s;
-            if (MODE == MODE_P && g == NG - 1) break;      // the final state of cumsum(prob) is not needed
-            bool ok = true;
-            uint64_t o = rec_step(grec[g], s, ok);
-            if (!ok) {
-                o = s;
-                const int b0 = g * G, b1 = (b0 + G < B) ? b0 + G : B;
-                for (int b = b0; b < b1; b++) o = block_out_exact<MODE>(br[b], w, nw, total, b, o, lit);
+        if (nb > MAXBND) sm.fail = 1;
+        else {
+            uint64_t s = 0;
+            sm.seg_start[0] = s;
+            for (int k = 0; k < nb; k++) {
+                uint64_t e = pure_step(sm.bnd_excl[k], s);
+                sm.bnd_ent[k] = e;
+                const int tt = sm.bnd_lane[k];
+                const int q0 = tt * CB, q1 = (q0 + CB < B) ? q0 + CB : B;
+                for (int b = q0; b < q1; b++) {
+                    cin[b] = e;                                        // boundary chunks are finished here
+                    if (b + 1 < B || MODE == MODE_W) e = block_out_exact<MODE>(br[b], side, w, nw, total, b, e, lit);
+                }
+                if (q1 == B) final_state = e;
+                s = e;
+                sm.seg_start[k + 1] = s;
             }
-            s = o;
         }
-        final_state = s;
     }
     __syncthreads();
-    if (t < NG) {
-        uint64_t s = gin[t];
-        const int b0 = t * G, b1 = (b0 + G < B) ? b0 + G : B;
-        for (int b = b0; b < b1; b++) {
-            cin[b] = s;
-            if (b + 1 < b1) s = block_out_exact<MODE>(br[b], w, nw, total, b, s, lit);
+    if (dbg == 14) return;
+    uint64_t ent = 0;
+    if (!sm.fail && c0 < B && !isb) {
+        ent = pure_step(exc, sm.seg_start[seg]);
+        const long long diff = (long long)(ent - cbase);
+        if (diff < wlo || diff > whi) sm.fail = 1;
+    }
+    __syncthreads();
+    if (sm.fail) {
+        // records did not cover the exact states: one lane walks every block (each step is still exact)
+        if (t == 0) {
+            uint64_t s = 0;
+            for (int b = 0; b < B; b++) { cin[b] = s; s = block_out_exact<MODE>(br[b], side, w, nw, total, b, s, lit); }
+            final_state = s;
+            atomicAdd((unsigned long long*)&st->stat_serial_walks, 1ull);
         }
+    } else if (c0 < B && !isb) {
+        uint64_t s = ent;
+        for (int b = c0; b < c1; b++) {
+            cin[b] = s;
+            if (b + 1 < c1 || (c1 == B && MODE == MODE_W)) s = block_out_exact<MODE>(br[b], side, w, nw, total, b, s, lit);
+        }
+        if (c1 == B) final_state = s;
     }
     if (lit) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
+    __syncthreads();
     if (MODE == MODE_W) {
         const double tot = b2d(final_state);
         if (t == 0) {
@@ -585,7 +1043,7 @@ __global__ __launch_bounds__(NT) void k_resolve(const double* __restrict__ w, lo
             if (tot == 0.0) atomicOr(&st->flags, FLAG_ZERO_SUM);       // src/resampling.cpp:8,22,49
             if (!isfinite(tot)) atomicOr(&st->flags, FLAG_NONFINITE);
         }
-        for (int b = t; b < B; b += NT) ain_p[b] = ain_w[b] / tot;
+        for (int b = t; b < B; b += NTR) ain_p[b] = ain_w[b] / tot;
     }
 }
 
@@ -620,56 +1078,33 @@ template <int KIND>
 __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
 {
     if (st->dead || !st->do_resample || st->flags) return;
-    __shared__ ScanSmem sm;
+    __shared__ SegSmem sm;
+    __shared__ uint64_t tin[NT];
     __shared__ int Tl[EB];
-    __shared__ int first_bad;
     __shared__ int Tbegin;
     const int t = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * EB;
     const double total = b2d(st->total_bits);
     const int call = st->cur_call;
+    const int dbg = st->debug_stop;
     double v[EL];
     load_terms<MODE_P>(a.w, a.nw, total, b0 + (long long)t * EL, v);
-    double ts = 0.0;
-#pragma unroll
-    for (int k = 0; k < EL; k++) ts += v[k];
-    const double h = a.ain_p[blockIdx.x] + block_excl_scan(ts, sm.sh4);
-    const Rec mine = chunk_record(v, EL, 1, h, a.lim);
-    Rec inc, exc;
-    if (t == 0) first_bad = NT;
-    scan_records(sm, mine, inc, exc);
-    const uint64_t cinb = a.cin[blockIdx.x];
-    uint64_t tin = cinb;
-    if (t > 0) {
-        bool ok = true;
-        tin = rec_step(exc, cinb, ok);
-        if (!ok) atomicMin(&first_bad, t);
-    }
-    sm.tin[t] = tin;
+    if (dbg == 1) { if (v[0] + v[7] == -1.0) Tl[t] = 1; return; }
+    BlockScan bs;
+    block_scan<MODE_P>(sm, v, a.ain_p[blockIdx.x], a.lim, bs);
     __syncthreads();
-    if (first_bad < NT) {
-        if (t == 0) {   // serial walk from the last thread whose exact state is known
-            uint64_t s = sm.tin[first_bad - 1];
-            long long lit = 0;
-            for (int tt = first_bad - 1; tt < NT; tt++) {
-                sm.tin[tt] = s;
-                bool ok = true;
-                uint64_t o = rec_step(sm.orig[tt], s, ok);
-                if (!ok) { o = literal_run<MODE_P>(a.w, a.nw, total, b0 + (long long)tt * EL, b0 + (long long)(tt + 1) * EL, s); lit += EL; }
-                s = o;
-            }
-            atomicAdd((unsigned long long*)&st->stat_serial_walks, 1ull);
-            atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
-        }
-        __syncthreads();
-        tin = sm.tin[t];
-    }
+    if (dbg == 2) { if (bs.exc.d0 == -12345) Tl[t] = 1; return; }
+    const uint64_t cinb = a.cin[blockIdx.x];
+    uint64_t ent;
+    const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
+    if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
+    if (dbg == 3) { if (ent == 12345) Tl[t] = 1; return; }
     // the reference chain itself, from the exact incoming state
     UniformSrc us;
     us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
     us.key = a.key; us.call = (uint32_t)call;
     const double Usys = (KIND == 1) ? us(0) : 0.0;
-    double c = b2d(tin);
+    double c = b2d(ent);
 #pragma unroll
     for (int k = 0; k < EL; k++) {
         c = c + v[k];
@@ -683,6 +1118,7 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
         Tl[t * EL + k] = T;
     }
     if (KIND == 2) return;                                            // multinomial: k_multinomial searches cum_out
+    if (dbg == 4) return;
     if (t == 0) {
         int tb = 0;
         if (blockIdx.x > 0) {
@@ -828,7 +1264,7 @@ __global__ void k_dump_uniforms(PhiloxKey key, uint32_t call, long long n, doubl
 __global__ void k_reset_state(DevState* st)
 {
     st->loglike = 0.0; st->lse_max = 0.0; st->lse_sum = 0.0; st->ess = 0.0; st->total_bits = 0;
-    st->do_resample = 0; st->dead = 0; st->flags = 0; st->res_calls = 0; st->cur_call = 0; st->pad0 = 0;
+    st->do_resample = 0; st->dead = 0; st->flags = 0; st->res_calls = 0; st->cur_call = 0; st->debug_stop = 0;
     st->stat_hard_blocks = 0; st->stat_serial_walks = 0; st->stat_literal_terms = 0;
 }
 

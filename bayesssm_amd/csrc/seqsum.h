@@ -138,6 +138,47 @@ BSSM_HD Rec chunk_record(const double* v, int L, int vs, double h, int32_t lim)
     return r;
 }
 
+// Fixed-length variant for the kernels: the loop is fully unrolled so that the
+// terms stay in registers (a runtime-length loop would put v[] in scratch).
+template <int L>
+BSSM_HD Rec chunk_record_fixed(const double (&v)[L], double h, int32_t lim)
+{
+    Rec r; r.pad = 0;
+    if (h == 0.0) {
+        double c = 0.0;
+#pragma unroll
+        for (int k = 0; k < L; k++) c = c + v[k];
+        r.base = 0; r.kind = REC_ABS; r.lo = 0; r.hi = 0;
+        r.o[0] = r.o[1] = r.o[2] = r.o[3] = d2b(c);
+        return r;
+    }
+    const uint64_t hb = d2b(h) & ~3ull;
+    const uint64_t near = (uint64_t)lim + 8;
+    bool hard = near_pow2(hb, near);
+    double c0 = b2d(hb), c1 = b2d(hb + 1), c2 = b2d(hb + 2), c3 = b2d(hb + 3);
+    uint64_t eprev = hb >> 52, bprev = hb;
+    int ncross = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        const double p = v[k];
+        c0 = c0 + p; c1 = c1 + p; c2 = c2 + p; c3 = c3 + p;
+        const uint64_t b0 = d2b(c0);
+        const uint64_t e = b0 >> 52;
+        if (e != eprev) {
+            hard = hard || (e - eprev != 1) || near_pow2(bprev, near) || near_pow2(b0, near);
+            ncross += 1;
+            eprev = e;
+        }
+        bprev = b0;
+    }
+    hard = hard || near_pow2(bprev, near) || ncross > 1;
+    if (hard) return rec_hard(hb);
+    r.base = hb; r.o[0] = d2b(c0); r.o[1] = d2b(c1); r.o[2] = d2b(c2); r.o[3] = d2b(c3);
+    r.kind = ncross ? REC_X1 : REC_PURE;
+    r.lo = -lim; r.hi = lim;
+    return r;
+}
+
 // Apply a record to the exact incoming bit pattern.  ok=false => the record
 // does not cover this state; the caller must run the terms literally.
 BSSM_HD uint64_t rec_step(const Rec& r, uint64_t in, bool& ok)
@@ -215,6 +256,12 @@ BSSM_HD int32_t count_le_systematic(double c, int32_t n, double U)
 {
     const double dn = (double)n;
     double g = c * dn - U;
+    {   // Fast path.  u_i = (i+U)/n (1+e), |e| <= 2^-52, and g = c n - U carries an error <= n 2^-52, so
+        // "u_i <= c" is decided by "i <= g" whenever g is further than n 2^-49 from an integer.
+        const double delta = dn * 0x1.0p-49;
+        const double fl = floor(g), fr = g - fl;
+        if (g > delta && g < dn - 1.0 && fr > delta && fr < 1.0 - delta) return (int32_t)fl + 1;
+    }
     int64_t t = (g < 0) ? 0 : (g >= dn ? (int64_t)n : (int64_t)g + 1);
     if (t > n) t = n;
     // pred(i): u_i <= c, true for small i, false for large i
@@ -229,6 +276,15 @@ BSSM_HD int32_t count_le_stratified(double c, int32_t n, const UF& U)
 {
     const double dn = (double)n;
     double g = c * dn;
+    {   // Fast path: outputs below floor(g) are certainly <= c, those above certainly not (U in [0,1));
+        // only output floor(g) needs the reference expression itself.
+        const double delta = dn * 0x1.0p-49;
+        const double fl = floor(g), fr = g - fl;
+        if (g > 1.0 && g < dn - 1.0 && fr > delta && fr < 1.0 - delta) {
+            const int32_t i0 = (int32_t)fl;
+            return i0 + ((((double)i0 + U(i0)) / dn) > c ? 0 : 1);
+        }
+    }
     int64_t t = (g < 0) ? 0 : (g >= dn ? (int64_t)n : (int64_t)g);
     if (t > n) t = n;
     while (t < n && !((((double)t + U((int32_t)t)) / dn) > c)) t++;

@@ -65,6 +65,7 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
     ph = np.zeros((T + 1, N)) if return_particles else None
     wh = np.zeros((T + 1, N)) if return_particles else None
     ms = np.zeros(1)
+    scan_stats = np.zeros(3, dtype=np.int64)
     zi = zt = ur = None
     if draws is not None:
         zi = np.ascontiguousarray(draws["z_init"], dtype=np.float64)
@@ -77,7 +78,7 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
                         _ptr(theta), int(theta.size), _ptr(y), _ptr(ot), int(seed), int(stream),
                         _ptr(zi), _ptr(zt), _ptr(ur), 1 if return_particles else 0, 1 if return_ancestors else 0)
     res = _lib.PfResult(_ptr(state_est), _ptr(ess), _ptr(llh), _ptr(ll), _ptr(ers), _ptr(nres), _ptr(resampled),
-                        _ptr(anc), _ptr(ph), _ptr(wh), _ptr(ms))
+                        _ptr(anc), _ptr(ph), _ptr(wh), _ptr(ms), _ptr(scan_stats))
     st = _lib.load().bssm_pf_run(ctx.handle, C.byref(cfg), C.byref(res))
     if st in (_lib.ERR_NEGATIVE, _lib.ERR_ZERO_SUM):
         raise ValueError(_lib.load().bssm_status_string(st).decode())
@@ -93,7 +94,7 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
         out["weights_history"] = wh[:rows]
     # extras (not in the reference's list): diagnostics for tests and benches
     out["_extras"] = {"device_ms": float(ms[0]), "n_res_calls": int(nres[0]), "early_return_step": early,
-                      "resampled": resampled[:T]}
+                      "resampled": resampled[:T], "scan_stats": scan_stats}
     if return_ancestors:
         out["_extras"]["ancestors"] = anc[: int(nres[0])]
     return out

@@ -138,6 +138,8 @@ def main():
                                    "resampling, return_particles=FALSE, device generator" % (T, N, args.resample_fn),
                        "per_gpu": "one independent filter replica per GPU (no data-path collective)"},
             "loglike_last_run": last["loglike"],
+            "scan_stats_last_run": dict(zip(("literal_tail_blocks", "serial_walks", "literal_terms"),
+                                            [int(v) for v in last["_extras"]["scan_stats"]])),
             "sweep": {"device_ms_per_run": per_run_ms, "us_per_observation": 1e3 * per_run_ms / T,
                       "algorithmic_bytes_per_particle_step": SWEEP_BYTES, "achieved_GBs": sweep_gbs,
                       "frac_of_hbm_peak": sweep_gbs / HBM_PEAK_GBS,

@@ -149,6 +149,7 @@ typedef struct {
     double* particles_history;/* (T+1) x (N d) row-major rows = as.numeric(N x d), or NULL */
     double* weights_history;  /* (T+1) x N, or NULL                            */
     double* device_ms;        /* 1 or NULL: HIP-event time of the run on the stream */
+    long long* scan_stats;    /* 3 or NULL: {blocks with a literal tail, serial walks, literal terms} summed over the run */
 } bssm_pf_result;
 
 int bssm_pf_run(bssm_ctx* ctx, const bssm_pf_config* cfg, bssm_pf_result* res);
