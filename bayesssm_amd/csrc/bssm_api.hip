@@ -164,6 +164,13 @@ extern "C" void* bssm_ctx_stream(bssm_ctx* c) { return c ? (void*)c->stream : nu
 static int g_debug_stop = 0;
 extern "C" void bssm_debug_set_stop(int stage) { g_debug_stop = stage; }
 __global__ void k_set_debug(DevState* st, int v) { st->debug_stop = v; }
+extern "C" int bssm_debug_get_stamps(bssm_ctx* c, long long* out /* [4][16] */)
+{
+    DevState h;
+    if (hipMemcpy(&h, c->st, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    memcpy(out, h.stamps, sizeof(h.stamps));
+    return 0;
+}
 
 extern "C" int bssm_ctx_set_profile(bssm_ctx* c, int enable)
 {
@@ -412,11 +419,11 @@ static void launch_step(bssm_ctx* c, bool trans, int weight, bool subaux, double
                         const ModelPar& par, double y, const NoiseSrc& ns)
 {
 #define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->st
-    if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step<trans+weight>", (k_step<MODEL, true, 1, false>), B, NT, 0, STEP_ARGS);
-    else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step<trans+weight-aux>", (k_step<MODEL, true, 1, true>), B, NT, 0, STEP_ARGS);
-    else if (trans && weight == 0) LAUNCH(c, "k_step<trans>", (k_step<MODEL, true, 0, false>), B, NT, 0, STEP_ARGS);
+    if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step<trans+weight>", (k_step<MODEL, true, 1, false>), B, NTS, 0, STEP_ARGS);
+    else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step<trans+weight-aux>", (k_step<MODEL, true, 1, true>), B, NTS, 0, STEP_ARGS);
+    else if (trans && weight == 0) LAUNCH(c, "k_step<trans>", (k_step<MODEL, true, 0, false>), B, NTS, 0, STEP_ARGS);
     else if (!trans && weight == 2) {
-        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NT, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->st);
+        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NTS, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->st);
     }
 #undef STEP_ARGS
 }
@@ -528,8 +535,8 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         } else if (gap <= 0) {
             // obs_times repeats a time: no transition, weights on the current particles
             NoiseSrc ns = noise(0);
-            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NT, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
-            else LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NT, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
+            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
+            else LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
         }
         double* se_row = separt + (size_t)i * B * dim;
         // normalise (:204-207) + loglik/ESS/decision (:208-218) + resample (:220-224), fused into the scan kernels

@@ -61,23 +61,81 @@ struct DevState {
     int32_t cur_call;             // index of the resample call in flight
     int32_t debug_stop;           // dev tool: kernels return after stage N (0 = run everything)
     long long stat_hard_blocks, stat_serial_walks, stat_literal_terms;
+    long long stamps[4][16];      // dev tool: clock64() at stage boundaries (debug_stop == 99)
 };
+
+#define BSSM_STAMP(st, dbg, row, col, cond) do { if ((dbg) == 99 && (cond)) (st)->stamps[row][col] = clock64(); } while (0)
 
 // ---------------------------------------------------------------------------
 // small block-level helpers (wave64 shuffles, then LDS across the 4 waves)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
+// Cross-lane moves by DPP (data-parallel primitives: a VALU operand modifier, a few cycles) instead of
+// ds_bpermute shuffles (an LDS-crossbar round trip each).  gfx9-family controls: row_shr:n shifts inside
+// a row of 16 lanes; row_bcast:15 / row_bcast:31 hand the last lane of a row / of the lower half-wave to
+// the following rows; wave_shr:1 shifts the whole wave64 by one lane.  Lanes without a source keep `old`.
+constexpr int DPP_SHR1 = 0x111, DPP_SHR2 = 0x112, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118;
+constexpr int DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
+
+template <int CTRL, int RM>
+__device__ __forceinline__ int dpp_i32(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, RM, 0xf, false); }
+template <int CTRL, int RM>
+__device__ __forceinline__ int64_t dpp_i64(int64_t old, int64_t src)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    const int lo = dpp_i32<CTRL, RM>((int)(uint32_t)(uint64_t)old, (int)(uint32_t)(uint64_t)src);
+    const int hi = dpp_i32<CTRL, RM>((int)(uint32_t)((uint64_t)old >> 32), (int)(uint32_t)((uint64_t)src >> 32));
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
-__device__ __forceinline__ double wave_max(double v)
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_f64(double old, double src)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
-    return v;
+    return __longlong_as_double(dpp_i64<CTRL, RM>(__double_as_longlong(old), __double_as_longlong(src)));
 }
+
+// inclusive wave64 scans / reductions; every lane must be active
+#define BSSM_WAVE_SCAN_STEPS(STEP) STEP(DPP_SHR1, 0xf) STEP(DPP_SHR2, 0xf) STEP(DPP_SHR4, 0xf) STEP(DPP_SHR8, 0xf) STEP(DPP_BCAST15, 0xa) STEP(DPP_BCAST31, 0xc)
+
+__device__ __forceinline__ double wave_incl_sum(double x)
+{
+#define STEP(C, R) x = dpp_f64<C, R>(0.0, x) + x;
+    BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
+    return x;
+}
+__device__ __forceinline__ double wave_incl_max(double x)
+{
+#define STEP(C, R) x = fmax(dpp_f64<C, R>(-INFINITY, x), x);
+    BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
+    return x;
+}
+__device__ __forceinline__ int64_t wave_incl_min_i64(int64_t x)
+{
+#define STEP(C, R) { const int64_t y = dpp_i64<C, R>(x, x); x = y < x ? y : x; }
+    BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
+    return x;
+}
+__device__ __forceinline__ int64_t wave_incl_max_i64(int64_t x)
+{
+#define STEP(C, R) { const int64_t y = dpp_i64<C, R>(x, x); x = y > x ? y : x; }
+    BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
+    return x;
+}
+__device__ __forceinline__ double lane63_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)b, 63), hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)b >> 32), 63);
+    return __longlong_as_double((long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+__device__ __forceinline__ int64_t lane63_i64(int64_t b)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)b, 63), hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)b >> 32), 63);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+// wave totals, valid in every lane
+__device__ __forceinline__ double wave_sum(double v) { return lane63_f64(wave_incl_sum(v)); }
+__device__ __forceinline__ double wave_max(double v) { return lane63_f64(wave_incl_max(v)); }
 // result valid in every thread
 __device__ __forceinline__ double block_sum(double v, double* sh4)
 {
@@ -124,14 +182,8 @@ __device__ __forceinline__ double block_max_n(double v, double* sh)
 __device__ __forceinline__ double block_excl_scan(double x, double* sh4)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double inc = x;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double y = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += y;
-    }
-    double exc = __shfl_up(inc, 1, 64);
-    if (lane == 0) exc = 0.0;
+    const double inc = wave_incl_sum(x);
+    const double exc = dpp_f64<DPP_WAVE_SHR1, 0xf>(0.0, inc);        // lane 0 keeps 0
     __syncthreads();
     if (lane == 63) sh4[wave] = inc;
     __syncthreads();
@@ -233,57 +285,55 @@ __global__ __launch_bounds__(NT) void k_init(double* __restrict__ x, long long N
 //   WEIGHT 2: lw = aux log-lik at the CURRENT particles  (:142-147), no transition
 //   SUBAUX  : lw -= aux_lw[ancestor] (already gathered)  (:175)
 // ---------------------------------------------------------------------------
+constexpr int NTS = 1024;        // threads per workgroup of k_step: one particle PAIR per thread, 16 waves
+                                 // (the transcendental chains need the occupancy to hide their latency)
+
 template <int MODEL, bool TRANS, int WEIGHT, bool SUBAUX>
-__global__ __launch_bounds__(NT) void k_step(const double* xin, double* xout /* may alias xin */,
-                                             double* __restrict__ lw, const double* __restrict__ auxg,
-                                             long long N, ModelPar par, double y, NoiseSrc ns,
-                                             double* __restrict__ pm, double* __restrict__ ps,
-                                             const DevState* __restrict__ st)
+__global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /* may alias xin */,
+                                              double* __restrict__ lw, const double* __restrict__ auxg,
+                                              long long N, ModelPar par, double y, NoiseSrc ns,
+                                              double* __restrict__ pm, double* __restrict__ ps,
+                                              const DevState* __restrict__ st)
 {
     if (st->dead) return;
-    __shared__ double sh4[4];
-    const long long base = (long long)blockIdx.x * EB;
-    double lv[EL];
-    double m = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < EL / 2; r++) {
-        const long long j = base + 2 * (threadIdx.x + NT * r);
-        lv[2 * r] = lv[2 * r + 1] = -INFINITY;
-        if (j < N) {
-            const bool two = (j + 1 < N);
-            double x0 = xin[j], x1 = two ? xin[j + 1] : 0.0;
-            if (TRANS) {
-                double z0, z1;
-                if (ns.arr) { z0 = ns.arr[j]; z1 = two ? ns.arr[j + 1] : 0.0; }
-                else normal_pair(ns.key, ns.purpose, ns.call, 0, (uint32_t)(j >> 1), z0, z1);
-                x0 = Model<MODEL>::transition(x0, z0, par);
-                x1 = Model<MODEL>::transition(x1, z1, par);
-                xout[j] = x0;
-                if (two) xout[j + 1] = x1;
+    __shared__ double sh[NTS / 64];
+    const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
+    double l0 = -INFINITY, l1 = -INFINITY;
+    if (j < N) {
+        const bool two = (j + 1 < N);
+        double x0, x1;
+        if (two) { const double2 q = *reinterpret_cast<const double2*>(xin + j); x0 = q.x; x1 = q.y; }
+        else { x0 = xin[j]; x1 = 0.0; }
+        if (TRANS) {
+            double z0, z1;
+            if (ns.arr) { z0 = ns.arr[j]; z1 = two ? ns.arr[j + 1] : 0.0; }
+            else normal_pair(ns.key, ns.purpose, ns.call, 0, (uint32_t)(j >> 1), z0, z1);
+            x0 = Model<MODEL>::transition(x0, z0, par);
+            x1 = Model<MODEL>::transition(x1, z1, par);
+            if (two) { double2 q; q.x = x0; q.y = x1; *reinterpret_cast<double2*>(xout + j) = q; }
+            else xout[j] = x0;
+        }
+        if (WEIGHT) {
+            if (WEIGHT == 2) {
+                l0 = r_dnorm_log(y, Model<MODEL>::forecast(x0, par), par.sy, par.log_sy);
+                l1 = r_dnorm_log(y, Model<MODEL>::forecast(x1, par), par.sy, par.log_sy);
+            } else {
+                l0 = r_dnorm_log(y, x0, par.sy, par.log_sy);
+                l1 = r_dnorm_log(y, x1, par.sy, par.log_sy);
             }
-            if (WEIGHT) {
-                double l0, l1;
-                if (WEIGHT == 2) {
-                    l0 = r_dnorm_log(y, Model<MODEL>::forecast(x0, par), par.sy, par.log_sy);
-                    l1 = r_dnorm_log(y, Model<MODEL>::forecast(x1, par), par.sy, par.log_sy);
-                } else {
-                    l0 = r_dnorm_log(y, x0, par.sy, par.log_sy);
-                    l1 = r_dnorm_log(y, x1, par.sy, par.log_sy);
-                }
-                if (SUBAUX) { l0 = l0 - auxg[j]; if (two) l1 = l1 - auxg[j + 1]; }
-                lw[j] = l0; lv[2 * r] = l0; m = fmax(m, l0);
-                if (two) { lw[j + 1] = l1; lv[2 * r + 1] = l1; m = fmax(m, l1); }
-            }
+            if (SUBAUX) { l0 = l0 - auxg[j]; if (two) l1 = l1 - auxg[j + 1]; }
+            if (two) { double2 q; q.x = l0; q.y = l1; *reinterpret_cast<double2*>(lw + j) = q; }
+            else { lw[j] = l0; l1 = -INFINITY; }
         }
     }
     if (WEIGHT) {
-        const double bm = block_max(m, sh4);
+        const double bm = block_max_n<NTS / 64>(fmax(l0, l1), sh);
         double s = 0.0;
         if (bm > -INFINITY) {
-#pragma unroll
-            for (int k = 0; k < EL; k++) if (lv[k] > -INFINITY) s += exp(lv[k] - bm);
+            if (l0 > -INFINITY) s += exp(l0 - bm);
+            if (l1 > -INFINITY) s += exp(l1 - bm);
         }
-        s = block_sum(s, sh4);
+        s = block_sum_n<NTS / 64>(s, sh);
         if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; }
     }
 }
@@ -421,14 +471,21 @@ __global__ __launch_bounds__(NT) void k_plan(const double* __restrict__ pm, cons
 // ---------------------------------------------------------------------------
 struct Pure { int64_t d0, d1; };
 
+// (bit-mask selects, not ?: on struct members: the compiler turns the latter into an indexed load and
+//  keeps the whole record in scratch memory)
+__device__ __forceinline__ int64_t sel_i64(int64_t a, int64_t b, uint64_t odd)
+{
+    const uint64_t m = 0ull - (odd & 1ull);
+    return (int64_t)(((uint64_t)a & ~m) | ((uint64_t)b & m));
+}
 __device__ __forceinline__ Pure pure_compose(const Pure& f, const Pure& g)
 {
     Pure c;
-    c.d0 = f.d0 + ((f.d0 & 1) ? g.d1 : g.d0);
-    c.d1 = f.d1 + (((f.d1 + 1) & 1) ? g.d1 : g.d0);
+    c.d0 = f.d0 + sel_i64(g.d0, g.d1, (uint64_t)f.d0);
+    c.d1 = f.d1 + sel_i64(g.d0, g.d1, (uint64_t)f.d1 + 1ull);
     return c;
 }
-__device__ __forceinline__ uint64_t pure_step(const Pure& f, uint64_t in) { return in + (uint64_t)((in & 1) ? f.d1 : f.d0); }
+__device__ __forceinline__ uint64_t pure_step(const Pure& f, uint64_t in) { return in + (uint64_t)sel_i64(f.d0, f.d1, in); }
 
 __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off)
 {
@@ -438,7 +495,7 @@ __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off)
 }
 
 struct SegSmem {
-    Pure wagg[16]; int wflag[16]; int wnb[16];
+    Pure wagg[16]; int wflag[16]; int wnb[16]; Pure wcarry[17]; int wsegbase[17];
     Pure bnd_excl[MAXBND]; Rec bnd_rec[MAXBND]; int bnd_lane[MAXBND]; uint64_t bnd_ent[MAXBND];
     uint64_t seg_start[MAXBND + 1];
     uint64_t lane_exit[4];       // exit state of the last lane of each wave (only [3] is used)
@@ -462,46 +519,48 @@ __device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, boo
     const unsigned long long bal = __ballot(isb);
     const unsigned long long below = bal & ((1ull << lane) - 1ull);
     // head flag: the previous lane is a boundary (lane 0 of a wave: decided across waves)
-    bool f = (lane > 0) && ((bal >> (lane - 1)) & 1ull);
     Pure v; v.d0 = isb ? 0 : leaf.d0; v.d1 = isb ? 0 : leaf.d1;
-    int fi = f ? 1 : 0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        Pure pv; pv.d0 = shfl_up_i64(v.d0, off); pv.d1 = shfl_up_i64(v.d1, off);
-        const int pf = __shfl_up(fi, off, 64);
-        if (lane >= off && !fi) { v = pure_compose(pv, v); fi = pf; }
-    }
+    int fi = ((lane > 0) && ((bal >> (lane - 1)) & 1ull)) ? 1 : 0;
+    // segmented inclusive scan: combine(prev, cur) = cur.f ? cur : (prev.v . cur.v, prev.f)
+#define STEP(C, R) { Pure pv; pv.d0 = dpp_i64<C, R>(0, v.d0); pv.d1 = dpp_i64<C, R>(0, v.d1); const int pf = dpp_i32<C, R>(0, fi); \
+                     if (!fi) { v = pure_compose(pv, v); fi = pf; } }
+    BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
     // v = composite from the segment head (or the wave start) up to and including this lane
+    const bool last_is_b = (bal >> 63) & 1ull;
     if (lane == 63) {
-        sm.wagg[wave] = v; sm.wflag[wave] = (bal != 0ull) ? 1 : 0;   // a boundary anywhere in the wave cuts the carry
+        Pure a = v;
+        if (last_is_b) { a.d0 = 0; a.d1 = 0; }                        // a boundary in the last lane: nothing is carried
+        sm.wagg[wave] = a; sm.wflag[wave] = (bal != 0ull) ? 1 : 0;    // a boundary anywhere in the wave cuts the carry
         sm.wnb[wave] = __popcll(bal);
     }
-    // NOTE: if the wave's LAST lane is a boundary the carry into the next wave is the identity
-    const bool last_is_b = (bal >> 63) & 1ull;
-    if (lane == 63 && last_is_b) { sm.wagg[wave].d0 = 0; sm.wagg[wave].d1 = 0; }
     __syncthreads();
-    Pure carry; carry.d0 = 0; carry.d1 = 0;
-    int segbase = 0;
-    for (int w = 0; w < wave; w++) {
-        if (sm.wflag[w]) carry = sm.wagg[w]; else carry = pure_compose(carry, sm.wagg[w]);
-        segbase += sm.wnb[w];
+    // carries across waves: wave 0 scans the NW wave aggregates (segmented) and publishes exclusive carries
+    if (wave == 0) {
+        Pure a; a.d0 = 0; a.d1 = 0; int af = 0, an = 0;
+        if (lane < NW) { a = sm.wagg[lane]; af = sm.wflag[lane]; an = sm.wnb[lane]; }
+        int cn = an;
+#define STEP(C, R) { Pure pv; pv.d0 = dpp_i64<C, R>(0, a.d0); pv.d1 = dpp_i64<C, R>(0, a.d1); const int pf = dpp_i32<C, R>(0, af); \
+                     cn += dpp_i32<C, R>(0, cn); if (!af) { a = pure_compose(pv, a); af = pf; } }
+        STEP(DPP_SHR1, 0xf) STEP(DPP_SHR2, 0xf) STEP(DPP_SHR4, 0xf) STEP(DPP_SHR8, 0xf)
+#undef STEP
+        // inclusive over waves 0..lane; exclusive = previous lane's
+        Pure e; e.d0 = dpp_i64<DPP_WAVE_SHR1, 0xf>(0, a.d0); e.d1 = dpp_i64<DPP_WAVE_SHR1, 0xf>(0, a.d1);
+        const int en = dpp_i32<DPP_WAVE_SHR1, 0xf>(0, cn);
+        if (lane < NW) { sm.wcarry[lane] = e; sm.wsegbase[lane] = en; }
+        if (lane == NW - 1) { sm.wcarry[NW] = a; sm.wsegbase[NW] = cn; }
     }
-    nb_total = 0;
-    for (int w = 0; w < NW; w++) nb_total += sm.wnb[w];
-    {   // composite of the block's LAST segment, through the last lane
-        Pure c; c.d0 = 0; c.d1 = 0;
-        for (int w = 0; w < NW; w++) { if (sm.wflag[w]) c = sm.wagg[w]; else c = pure_compose(c, sm.wagg[w]); }
-        block_incl_last_seg = c;
-    }
-    // inclusive value with the carry from earlier waves (lanes before the wave's first boundary)
+    __syncthreads();
+    const Pure carry = sm.wcarry[wave];
+    const int segbase = sm.wsegbase[wave];
+    nb_total = sm.wsegbase[NW];
+    block_incl_last_seg = sm.wcarry[NW];
     // lanes at or before the first boundary of the wave (inclusive of that boundary lane) still belong to the carried segment
     const bool carried = (below == 0ull);
-    Pure inc = carried ? pure_compose(carry, v) : v;
+    const Pure inc = carried ? pure_compose(carry, v) : v;
     // exclusive = inclusive of the previous lane, unless the previous lane is a boundary
-    Pure exc; exc.d0 = shfl_up_i64(inc.d0, 1); exc.d1 = shfl_up_i64(inc.d1, 1);
-    if (lane == 0) exc = carry;
+    Pure exc; exc.d0 = dpp_i64<DPP_WAVE_SHR1, 0xf>(carry.d0, inc.d0); exc.d1 = dpp_i64<DPP_WAVE_SHR1, 0xf>(carry.d1, inc.d1);
     if (lane > 0 && ((bal >> (lane - 1)) & 1ull)) { exc.d0 = 0; exc.d1 = 0; }
-    // lane 0 of a wave whose predecessor (lane 63 of the previous wave) is a boundary: carry is already the identity
     seg = segbase + __popcll(below);
     return exc;
 }
@@ -630,22 +689,10 @@ __device__ __forceinline__ void block_literal(uint64_t* tin /* LDS [NT] */, uint
 __device__ __forceinline__ void block_minmax2(SegSmem& sm, long long mn[2], long long mx[2])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            int lo = (int)(uint32_t)(uint64_t)mn[s], hi = (int)(uint32_t)((uint64_t)mn[s] >> 32);
-            lo = __shfl_down(lo, off, 64); hi = __shfl_down(hi, off, 64);
-            const long long o = (long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-            mn[s] = (o < mn[s]) ? o : mn[s];
-            lo = (int)(uint32_t)(uint64_t)mx[s]; hi = (int)(uint32_t)((uint64_t)mx[s] >> 32);
-            lo = __shfl_down(lo, off, 64); hi = __shfl_down(hi, off, 64);
-            const long long p = (long long)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-            mx[s] = (p > mx[s]) ? p : mx[s];
-        }
-    }
+    const long long a0 = lane63_i64(wave_incl_min_i64(mn[0])), a1 = lane63_i64(wave_incl_min_i64(mn[1]));
+    const long long b0 = lane63_i64(wave_incl_max_i64(mx[0])), b1 = lane63_i64(wave_incl_max_i64(mx[1]));
     __syncthreads();
-    if (lane == 0) { sm.red_min[wave][0] = mn[0]; sm.red_min[wave][1] = mn[1]; sm.red_max[wave][0] = mx[0]; sm.red_max[wave][1] = mx[1]; }
+    if (lane == 0) { sm.red_min[wave][0] = a0; sm.red_min[wave][1] = a1; sm.red_max[wave][0] = b0; sm.red_max[wave][1] = b1; }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -694,29 +741,35 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
     const long long b0 = (long long)blockIdx.x * EB;
     const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
     const int dbg = st->debug_stop;
+    const bool stamper = (t == 0 && blockIdx.x == 100);
+    BSSM_STAMP(st, dbg, 2, 0, stamper);
     double v[EL];
     double a_in;
     if (FROM_LW) {
-        double M, S;
-        reduce_lse_partials(f.pm, f.ps, f.nb, sm.sh4, M, S);
+        // global (max, sum exp) from the per-block partials, and -- from the same numbers -- the approximate
+        // exclusive block prefixes of w:  sum_b w = ps[b] exp(pm[b] - M) / S
+        __shared__ double es[MAXB];
+        double m = -INFINITY;
+        for (int i = t; i < f.nb; i += NT) m = fmax(m, f.pm[i]);
+        const double M = block_max(m, sm.sh4);
         if (f.check_degenerate && M < -1e8) return;          // degenerate: the resolve/plan step marks the run dead (:189)
-        // approximate block sums of w from the partials: sum_b = ps[b] exp(pm[b] - M) / S
-        double loc[MAXB / NT];
+        double se = 0.0;
+        for (int i = t; i < MAXB; i += NT) {
+            double x = 0.0;
+            if (i < f.nb) { const double mb = f.pm[i]; x = (mb > -INFINITY) ? f.ps[i] * exp(mb - M) : 0.0; }
+            es[i] = x; se += x;
+        }
+        const double S = block_sum(se, sm.sh4);              // (block_sum syncs: es[] is complete)
         double ts0 = 0.0;
 #pragma unroll
-        for (int k = 0; k < MAXB / NT; k++) {
-            const int i = t * (MAXB / NT) + k;
-            double x = 0.0;
-            if (i < f.nb) { const double mb = f.pm[i]; x = (mb > -INFINITY) ? f.ps[i] * exp(mb - M) / S : 0.0; }
-            loc[k] = x; ts0 += x;
-        }
+        for (int k = 0; k < MAXB / NT; k++) ts0 += es[t * (MAXB / NT) + k];
         double pre = block_excl_scan(ts0, sm.sh4);
 #pragma unroll
         for (int k = 0; k < MAXB / NT; k++) {
             const int i = t * (MAXB / NT) + k;
-            if (i == (int)blockIdx.x) sm.bcast = pre;
-            if (blockIdx.x == 0 && i < f.nb) f.ain_out[i] = pre;
-            pre += loc[k];
+            if (i == (int)blockIdx.x) sm.bcast = pre / S;
+            if (blockIdx.x == 0 && i < f.nb) f.ain_out[i] = pre / S;
+            pre += es[i];
         }
         __syncthreads();
         a_in = sm.bcast;
@@ -741,9 +794,11 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
         a_in = ain[blockIdx.x];
     }
     if (dbg == 1) { if (v[0] + v[7] == -1.0) tin[t] = 1; return; }
+    BSSM_STAMP(st, dbg, 2, 1, stamper && v[0] >= 0.0);
     BlockScan bs;
     block_scan<MODE>(sm, v, a_in, lim, bs);
     __syncthreads();
+    BSSM_STAMP(st, dbg, 2, 2, stamper);
     if (dbg == 2) { if (bs.exc.d0 == -12345) tin[t] = 1; return; }
     if (dbg == 3 && a_in == 0.0) return;
     const uint64_t hb0 = d2b(a_in) & ~3ull;
@@ -778,6 +833,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
         if (bs.seg == 0) { mn[0] = lo_; mx[0] = hi_; } else { mn[1] = lo_; mx[1] = hi_; }   // no runtime index: keeps mn/mx in registers
     }
     block_minmax2(sm, mn, mx);
+    BSSM_STAMP(st, dbg, 2, 3, stamper);
     // segment-0 prefix record: lanes [0, fb)
     if (bs.nb == 0) {
         if (t == NT - 1) {
@@ -918,7 +974,10 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     BlockRec* br = reinterpret_cast<BlockRec*>(smraw);
     __shared__ SegSmem sm;
     __shared__ uint64_t final_state;
+    __shared__ __attribute__((aligned(16))) SideEntry sideC[64];
     const int t = threadIdx.x;
+    const int dbg0 = st->debug_stop;
+    BSSM_STAMP(st, dbg0, MODE, 0, t == 0);
     if (MODE == MODE_W && pa.plan != PLAN_RESAMPLE_ONLY) {
         __shared__ int go;
         if (pa.plan == PLAN_PF) {
@@ -951,6 +1010,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     } else {
         if (!st->do_resample) return;
     }
+    BSSM_STAMP(st, dbg0, MODE, 1, t == 0);
     {   // stage the block records in LDS (16-byte pieces)
         const uint4* src = reinterpret_cast<const uint4*>(brec);
         uint4* dst = reinterpret_cast<uint4*>(smraw);
@@ -960,6 +1020,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     if (t == 0) sm.fail = 0;
     __syncthreads();
     const int dbg = st->debug_stop;
+    BSSM_STAMP(st, dbg0, MODE, 2, t == 0);
     if (dbg == 11) return;
     const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
     const int CB = (B + NTR - 1) / NTR;                // blocks per thread (1 or 2)
@@ -982,34 +1043,85 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
         comp = pure_compose(comp, p);
     }
     if (c0 >= B) { isb = false; comp.d0 = comp.d1 = 0; }    // padding lanes: identity
+    BSSM_STAMP(st, dbg0, MODE, 3, t == 0);
     if (dbg == 12) { if (comp.d0 == -12345) cin[0] = 1; return; }
     int seg, nb; Pure lastseg;
     const Pure exc = seg_excl_scan<NTR / 64>(sm, comp, isb, seg, nb, lastseg);
     if (isb && seg < MAXBND) { sm.bnd_excl[seg] = exc; sm.bnd_lane[seg] = t; }
     __syncthreads();
     if (dbg == 13) { if (exc.d0 == -12345) cin[0] = 1; return; }
+    BSSM_STAMP(st, dbg0, MODE, 4, t == 0);
     long long lit = 0;
-    if (t == 0) {
-        if (nb > MAXBND) sm.fail = 1;
+    // ---- boundary walk.  One wave; lane j owns the j-th boundary block with its record in registers; the
+    // exact state is handed from lane to lane by readlane, so each step costs one record evaluation. ----
+    const int nent = nb * CB;
+    if (t < 64) {
+        const int lane = t;
+        const bool fits = (nb <= MAXBND) && (nent <= 64);
+        const bool have = fits && lane < nent;
+        const int k = have ? lane / CB : 0;
+        int bidx = -1;
+        Pure ex; ex.d0 = 0; ex.d1 = 0;
+        if (have) {
+            bidx = sm.bnd_lane[k] * CB + (lane % CB);
+            if (bidx >= B) bidx = -1;
+            if (lane % CB == 0) ex = sm.bnd_excl[k];
+        }
+        Rec pr = rec_identity(0);
+        int nside = 0;
+        bool slow = false;
+        if (bidx >= 0) {
+            pr = br[bidx].prefix; nside = br[bidx].nside;
+            slow = (nside > 1) || (br[bidx].tail_from < NT);
+            if (nside == 1 && !slow && fits) {   // stage the single side entry in LDS (read only when it is this lane's turn)
+                const uint4* sp = reinterpret_cast<const uint4*>(&side[bidx].e[0]);
+                uint4* dp = reinterpret_cast<uint4*>(&sideC[lane]);
+#pragma unroll
+                for (int q = 0; q < (int)(sizeof(SideEntry) / 16); q++) dp[q] = sp[q];
+            }
+        }
+        if (!fits) { if (lane == 0) sm.fail = 1; }
         else {
-            uint64_t s = 0;
-            sm.seg_start[0] = s;
-            for (int k = 0; k < nb; k++) {
-                uint64_t e = pure_step(sm.bnd_excl[k], s);
-                sm.bnd_ent[k] = e;
-                const int tt = sm.bnd_lane[k];
-                const int q0 = tt * CB, q1 = (q0 + CB < B) ? q0 + CB : B;
-                for (int b = q0; b < q1; b++) {
-                    cin[b] = e;                                        // boundary chunks are finished here
-                    if (b + 1 < B || MODE == MODE_W) e = block_out_exact<MODE>(br[b], side, w, nw, total, b, e, lit);
+            uint64_t s = 0, my_in = 0, my_out = 0;
+            for (int j = 0; j < nent; j++) {
+                const uint64_t e = pure_step(ex, s);
+                uint64_t o = e;
+                bool ok = true;
+                if (bidx >= 0 && !slow) o = rec_step(pr, e, ok);
+                if (lane == j && bidx >= 0 && !slow && ok && nside == 1) {
+                    const SideEntry& se = sideC[lane];
+                    bool ok2 = true;
+                    uint64_t o2 = rec_step(se.leaf, o, ok2);
+                    if (!ok2) {                              // HARD leaf: its 8 terms literally (kept in the entry)
+                        double c = b2d(o);
+#pragma unroll
+                        for (int q = 0; q < EL; q++) c = c + se.terms[q];
+                        o2 = d2b(c);
+                    }
+                    o = o2;
+                    if (se.pad) {
+                        const int64_t diff = (int64_t)(o - se.post_base);
+                        if (diff < (int64_t)se.lo || diff > (int64_t)se.hi) ok = false;
+                        else { Pure pp; pp.d0 = se.d0; pp.d1 = se.d1; o = pure_step(pp, o); }
+                    }
                 }
-                if (q1 == B) final_state = e;
-                s = e;
-                sm.seg_start[k + 1] = s;
+                if (lane == j && bidx >= 0 && (slow || !ok))     // anything unusual: the general (slower) routine
+                    o = block_out_exact<MODE>(br[bidx], side, w, nw, total, bidx, e, lit);
+                if (lane == j) { my_in = e; my_out = o; }
+                const int olo = __shfl((int)(uint32_t)o, j, 64), ohi = __shfl((int)(uint32_t)(o >> 32), j, 64);
+                s = ((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo;
+            }
+            if (lane == 0) sm.seg_start[0] = 0;
+            if (have) {
+                if (bidx >= 0) cin[bidx] = my_in;                // boundary blocks are finished here
+                if (lane % CB == CB - 1) sm.seg_start[k + 1] = my_out;
+                if (bidx == B - 1) final_state = my_out;
             }
         }
     }
+    BSSM_STAMP(st, dbg0, MODE, 5, t == 0);
     __syncthreads();
+    BSSM_STAMP(st, dbg0, MODE, 6, t == 0);
     if (dbg == 14) return;
     uint64_t ent = 0;
     if (!sm.fail && c0 < B && !isb) {
@@ -1036,6 +1148,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     }
     if (lit) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
     __syncthreads();
+    BSSM_STAMP(st, dbg0, MODE, 7, t == 0);
     if (MODE == MODE_W) {
         const double tot = b2d(final_state);
         if (t == 0) {
@@ -1082,23 +1195,30 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     __shared__ uint64_t tin[NT];
     __shared__ int Tl[EB];
     __shared__ int Tbegin;
+    constexpr int OWN_CAP = 6144;
+    __shared__ unsigned short own[OWN_CAP];
     const int t = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * EB;
     const double total = b2d(st->total_bits);
     const int call = st->cur_call;
     const int dbg = st->debug_stop;
+    const bool stamper = (t == 0 && blockIdx.x == 100);
+    BSSM_STAMP(st, dbg, 3, 0, stamper);
     double v[EL];
     load_terms<MODE_P>(a.w, a.nw, total, b0 + (long long)t * EL, v);
     if (dbg == 1) { if (v[0] + v[7] == -1.0) Tl[t] = 1; return; }
+    BSSM_STAMP(st, dbg, 3, 1, stamper && v[0] >= 0.0);
     BlockScan bs;
     block_scan<MODE_P>(sm, v, a.ain_p[blockIdx.x], a.lim, bs);
     __syncthreads();
+    BSSM_STAMP(st, dbg, 3, 2, stamper);
     if (dbg == 2) { if (bs.exc.d0 == -12345) Tl[t] = 1; return; }
     const uint64_t cinb = a.cin[blockIdx.x];
     uint64_t ent;
     const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
     if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
     if (dbg == 3) { if (ent == 12345) Tl[t] = 1; return; }
+    BSSM_STAMP(st, dbg, 3, 3, stamper);
     // the reference chain itself, from the exact incoming state
     UniformSrc us;
     us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
@@ -1119,6 +1239,7 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     }
     if (KIND == 2) return;                                            // multinomial: k_multinomial searches cum_out
     if (dbg == 4) return;
+    BSSM_STAMP(st, dbg, 3, 4, stamper);
     if (t == 0) {
         int tb = 0;
         if (blockIdx.x > 0) {
@@ -1132,27 +1253,65 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     int* anc = a.anc_out ? a.anc_out + (long long)call * a.anc_stride : nullptr;
     const double invN = 1.0 / (double)a.n;
     double acc0 = 0.0, acc1 = 0.0;
-    for (int i = Tb + t; i < Te; i += NT) {
-        // first local index whose count exceeds i
-        int lo = 0, hi = EB - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (Tl[mid] > i) hi = mid; else lo = mid + 1;
-        }
-        const long long src = b0 + lo;
-        if (anc) anc[i] = (int)(src + 1);                            // 1-based (src/resampling.cpp:36,62)
-        if (a.xdst) {
-            const double x0 = a.xsrc[src];
-            a.xdst[i] = x0; acc0 += x0 * invN;
-            if (a.dim > 1) { const double x1 = a.xsrc[a.xstride + src]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
-        }
-        if (a.auxdst) a.auxdst[i] = a.auxsrc[src];
+    // Expansion.  Each element owns the outputs [T_prev, T) (src/resampling.cpp:30-37).  Common case (the
+    // block owns at most OWN_CAP outputs, no element more than 64): every lane writes the local index of
+    // its elements into the LDS slots of the outputs they own; the block then reads the slots back in
+    // output order, so the global gather/store is coalesced.  Otherwise: binary search in the counts.
+    const int nout = Te - Tb;
+    int tprev = (t == 0) ? Tb : Tl[t * EL - 1];
+    int maxcnt = 0;
+    {
+        int p = tprev;
+#pragma unroll
+        for (int k = 0; k < EL; k++) { const int T = Tl[t * EL + k]; maxcnt = (T - p) > maxcnt ? (T - p) : maxcnt; p = T; }
     }
+    const int any_big = __syncthreads_or(maxcnt > 64);
+    if (nout <= OWN_CAP && !any_big) {
+        int p = tprev;
+#pragma unroll
+        for (int k = 0; k < EL; k++) {
+            const int T = Tl[t * EL + k];
+            for (int i = p; i < T; i++) own[i - Tb] = (unsigned short)(t * EL + k);
+            p = T;
+        }
+        __syncthreads();
+        for (int r = t; r < nout; r += NT) {
+            const int lo = own[r];
+            const long long src = b0 + lo;
+            const int i = Tb + r;
+            if (anc) anc[i] = (int)(src + 1);                        // 1-based (src/resampling.cpp:36,62)
+            if (a.xdst) {
+                const double x0 = a.xsrc[src];
+                a.xdst[i] = x0; acc0 += x0 * invN;
+                if (a.dim > 1) { const double x1 = a.xsrc[a.xstride + src]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
+            }
+            if (a.auxdst) a.auxdst[i] = a.auxsrc[src];
+        }
+    } else {
+        for (int i = Tb + t; i < Te; i += NT) {
+            // first local index whose count exceeds i
+            int lo = 0, hi = EB - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (Tl[mid] > i) hi = mid; else lo = mid + 1;
+            }
+            const long long src = b0 + lo;
+            if (anc) anc[i] = (int)(src + 1);
+            if (a.xdst) {
+                const double x0 = a.xsrc[src];
+                a.xdst[i] = x0; acc0 += x0 * invN;
+                if (a.dim > 1) { const double x1 = a.xsrc[a.xstride + src]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
+            }
+            if (a.auxdst) a.auxdst[i] = a.auxsrc[src];
+        }
+    }
+    BSSM_STAMP(st, dbg, 3, 5, stamper);
     if (a.se_part) {
         acc0 = block_sum(acc0, sm.sh4);
         if (a.dim > 1) acc1 = block_sum(acc1, sm.sh4);
         if (t == 0) { a.se_part[(long long)blockIdx.x * a.dim] = acc0; if (a.dim > 1) a.se_part[(long long)blockIdx.x * a.dim + 1] = acc1; }
     }
+    BSSM_STAMP(st, dbg, 3, 6, stamper);
 }
 
 // multinomial: inverse CDF on the exact cum_sum (distributional parity only)

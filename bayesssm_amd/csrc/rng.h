@@ -11,7 +11,8 @@
 // header's stream can be dumped with bssm_dump_* to feed the CPU oracle).
 //
 // Philox4x32-10: Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy
-// as 1, 2, 3" (SC'11).  Normal deviates by inversion (as R's default
+// as 1, 2, 3" (SC'11).  Device normals: Box-Muller on the two uniforms of one
+// Philox block.  Host (PMMH proposal) normals: inversion (as R's default
 // "Inversion" normal.kind does) with Wichura's AS 241 PPND16 rational
 // approximation (Appl. Statist. 37 (1988) 477-484).
 #pragma once
@@ -96,15 +97,24 @@ BSSM_HD double qnorm_as241(double p)
 struct PhiloxKey { uint32_t k0, k1, stream; };   // key = seed; stream goes into counter word 3
 
 // Two standard normals for the index PAIR (2*pair, 2*pair+1), dimension `dim`,
-// of draw-call `call` with the given purpose.
-BSSM_HD void normal_pair(PhiloxKey key, uint32_t purpose, uint32_t call, uint32_t dim, uint32_t pair,
-                         double& z0, double& z1)
+// of draw-call `call` with the given purpose.  One Philox block = 128 bits = two
+// uniforms = one Box-Muller pair: no divergent tail branch, one log + sqrt +
+// sincospi per two deviates (the inversion above costs about twice as much per
+// deviate on a 64-wide wave because every wave runs both of its branches).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void normal_pair(PhiloxKey key, uint32_t purpose, uint32_t call, uint32_t dim, uint32_t pair,
+                                            double& z0, double& z1)
 {
     u32x4 c; c.x = pair; c.y = call; c.z = purpose | (dim << 8); c.w = key.stream;
     const u32x4 r = philox4x32_10(c, key.k0, key.k1);
-    z0 = qnorm_as241(u01_from_bits(r.x, r.y));
-    z1 = qnorm_as241(u01_from_bits(r.z, r.w));
+    const double u1 = u01_from_bits(r.x, r.y), u2 = u01_from_bits(r.z, r.w);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    z0 = rad * cs;
+    z1 = rad * sn;
 }
+#endif
 
 // Uniform (0,1) for output index i of resample call `call` (stratified /
 // multinomial); systematic uses index 0.
