@@ -80,9 +80,9 @@ def gather_chains(local, num_chains, m, p, dist=None):
     for slot, c in enumerate(chain_assignment(num_chains, world)[rank]):
         buf[slot] = torch.from_numpy(np.ascontiguousarray(local[c]))
     buf = buf.to(dev)
-    allbuf = torch.empty((world, per, m, p), dtype=torch.float64, device=dev)
+    allbuf = torch.empty((world * per, m, p), dtype=torch.float64, device=dev)     # ranks concatenated along dim 0
     dist.all_gather_into_tensor(allbuf, buf)
-    allbuf = allbuf.cpu().numpy()
+    allbuf = allbuf.cpu().numpy().reshape(world, per, m, p)
     for r, chains in enumerate(chain_assignment(num_chains, world)):
         for slot, c in enumerate(chains):
             out[c] = allbuf[r, slot]
