@@ -41,7 +41,7 @@ struct bssm_ctx {
     // particle state
     double *x0 = nullptr, *x1 = nullptr, *lw = nullptr, *w = nullptr, *auxlw = nullptr, *auxg = nullptr, *cum = nullptr;
     // scan workspace
-    double *pm = nullptr, *ps = nullptr, *bsum = nullptr, *bsq = nullptr, *ain_w = nullptr, *ain_p = nullptr;
+    double *pm = nullptr, *ps = nullptr, *pq = nullptr, *bsum = nullptr, *bsq = nullptr, *ain_w = nullptr, *ain_p = nullptr;
     BlockRec* brec = nullptr;
     SideList* side = nullptr;
     uint64_t* cin = nullptr;
@@ -116,7 +116,7 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
     A((void**)&c->x0, npad * 8 * max_dim); A((void**)&c->x1, npad * 8 * max_dim);
     A((void**)&c->lw, npad * 8); A((void**)&c->w, npad * 8); A((void**)&c->auxlw, npad * 8); A((void**)&c->auxg, npad * 8);
     A((void**)&c->cum, npad * 8);
-    A((void**)&c->pm, MAXB * 8); A((void**)&c->ps, MAXB * 8); A((void**)&c->bsum, MAXB * 8); A((void**)&c->bsq, MAXB * 8);
+    A((void**)&c->pm, MAXB * 8); A((void**)&c->ps, MAXB * 8); A((void**)&c->pq, MAXB * 8); A((void**)&c->bsum, MAXB * 8); A((void**)&c->bsq, MAXB * 8);
     A((void**)&c->ain_w, MAXB * 8); A((void**)&c->ain_p, MAXB * 8);
     A((void**)&c->brec, MAXB * sizeof(BlockRec)); A((void**)&c->cin, MAXB * 8);
     A((void**)&c->side, (size_t)B * sizeof(SideList));
@@ -139,7 +139,7 @@ extern "C" void bssm_ctx_destroy(bssm_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->x0, c->x1, c->lw, c->w, c->auxlw, c->auxg, c->cum, c->pm, c->ps, c->bsum, c->bsq,
+    void* ptrs[] = {c->x0, c->x1, c->lw, c->w, c->auxlw, c->auxg, c->cum, c->pm, c->ps, c->pq, c->bsum, c->bsq,
                     c->ain_w, c->ain_p, c->brec, c->side, c->cin, c->st};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->pool) if (kv.second.first) (void)hipFree(kv.second.first);
@@ -247,17 +247,14 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     const int B = (int)((r.nw + EB - 1) / EB);
     const int lim = rec_window(r.nw);
     const size_t shm = (size_t)B * sizeof(BlockRec);
-    FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.nb = B; f.bsq = c->bsq;
-    f.ain_out = c->ain_w; f.check_degenerate = r.check_degenerate;
-    PlanArgs pa; pa.plan = r.plan; pa.pm = c->pm; pa.ps = c->ps; pa.bsq = c->bsq; pa.nb = B; pa.N = r.nw; pa.obs_i = r.obs_i;
-    pa.resample_algorithm = r.resample_algorithm; pa.threshold = r.threshold; pa.ess_out = r.d_ess; pa.llh_out = r.d_llh;
-    pa.resampled_out = r.d_resampled;
-    PlanArgs pnone = pa; pnone.plan = PLAN_RESAMPLE_ONLY;
+    FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
+    f.ain_out = c->ain_w; f.plan = r.plan; f.N = r.nw; f.obs_i = r.obs_i; f.resample_algorithm = r.resample_algorithm;
+    f.threshold = r.threshold; f.ess_out = r.d_ess; f.llh_out = r.d_llh; f.resampled_out = r.d_resampled;
     if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f);
     else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f);
-    LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st, pa);
+    LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
     LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), B, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec, c->side, c->st, f);
-    LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st, pnone);
+    LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
     ApplyArgs a;
     a.w = r.d_w; a.nw = r.nw; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = r.n;
     a.u_base = r.d_u; a.u_stride = r.u_stride; a.key = r.key;
@@ -418,12 +415,12 @@ template <int MODEL>
 static void launch_step(bssm_ctx* c, bool trans, int weight, bool subaux, double* x, long long N, int B,
                         const ModelPar& par, double y, const NoiseSrc& ns)
 {
-#define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->st
+#define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st
     if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step<trans+weight>", (k_step<MODEL, true, 1, false>), B, NTS, 0, STEP_ARGS);
     else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step<trans+weight-aux>", (k_step<MODEL, true, 1, true>), B, NTS, 0, STEP_ARGS);
     else if (trans && weight == 0) LAUNCH(c, "k_step<trans>", (k_step<MODEL, true, 0, false>), B, NTS, 0, STEP_ARGS);
     else if (!trans && weight == 2) {
-        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NTS, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->st);
+        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NTS, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st);
     }
 #undef STEP_ARGS
 }
@@ -497,6 +494,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
 
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
+    if (g_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, g_debug_stop);
     {   // t = 0  (:76-116)
         NoiseSrc ns; ns.arr = (const double*)d_zi; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
         LAUNCH(c, "k_init", k_init, B, NT, 0, X0, N, ns, separt);
@@ -535,8 +533,8 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         } else if (gap <= 0) {
             // obs_times repeats a time: no transition, weights on the current particles
             NoiseSrc ns = noise(0);
-            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
-            else LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->st);
+            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st);
+            else LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st);
         }
         double* se_row = separt + (size_t)i * B * dim;
         // normalise (:204-207) + loglik/ESS/decision (:208-218) + resample (:220-224), fused into the scan kernels

@@ -292,10 +292,12 @@ template <int MODEL, bool TRANS, int WEIGHT, bool SUBAUX>
 __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /* may alias xin */,
                                               double* __restrict__ lw, const double* __restrict__ auxg,
                                               long long N, ModelPar par, double y, NoiseSrc ns,
-                                              double* __restrict__ pm, double* __restrict__ ps,
+                                              double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq,
                                               const DevState* __restrict__ st)
 {
-    if (st->dead) return;
+    // (no early return on st->dead here: a dependent read of the run state in front of the particle loads would
+    //  cost every launch a memory round trip; propagating a dead run is harmless, its results are never read)
+    (void)st;
     __shared__ double sh[NTS / 64];
     const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
     double l0 = -INFINITY, l1 = -INFINITY;
@@ -328,13 +330,14 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
     }
     if (WEIGHT) {
         const double bm = block_max_n<NTS / 64>(fmax(l0, l1), sh);
-        double s = 0.0;
+        double s = 0.0, q = 0.0;                       // sum exp(l - bm) and sum exp(l - bm)^2 (the latter feeds the ESS)
         if (bm > -INFINITY) {
-            if (l0 > -INFINITY) s += exp(l0 - bm);
-            if (l1 > -INFINITY) s += exp(l1 - bm);
+            if (l0 > -INFINITY) { const double e = exp(l0 - bm); s += e; q += e * e; }
+            if (l1 > -INFINITY) { const double e = exp(l1 - bm); s += e; q += e * e; }
         }
         s = block_sum_n<NTS / 64>(s, sh);
-        if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; }
+        q = block_sum_n<NTS / 64>(q, sh);
+        if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; }
     }
 }
 
@@ -497,6 +500,7 @@ __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off)
 struct SegSmem {
     Pure wagg[16]; int wflag[16]; int wnb[16]; Pure wcarry[17]; int wsegbase[17];
     Pure bnd_excl[MAXBND]; Rec bnd_rec[MAXBND]; int bnd_lane[MAXBND]; uint64_t bnd_ent[MAXBND];
+    double bnd_terms[MAXBND][EL];    // the terms of every boundary lane (so a literal re-run never chases global memory)
     uint64_t seg_start[MAXBND + 1];
     uint64_t lane_exit[4];       // exit state of the last lane of each wave (only [3] is used)
     long long red_min[4][2], red_max[4][2];
@@ -627,6 +631,8 @@ __device__ __forceinline__ void block_scan(SegSmem& sm, const double (&v)[EL], d
         d.base = bs.leaf.base; d.o[0] = bs.leaf.o[0]; d.o[1] = bs.leaf.o[1]; d.o[2] = bs.leaf.o[2]; d.o[3] = bs.leaf.o[3];
         d.kind = bs.leaf.kind; d.lo = bs.leaf.lo; d.hi = bs.leaf.hi; d.pad = 0;
         sm.bnd_excl[bs.seg].d0 = bs.exc.d0; sm.bnd_excl[bs.seg].d1 = bs.exc.d1; sm.bnd_lane[bs.seg] = threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < EL; q++) sm.bnd_terms[bs.seg][q] = v[q];
     }
 }
 
@@ -641,18 +647,30 @@ __device__ __forceinline__ bool block_resolve(SegSmem& sm, const BlockScan& bs, 
     const int t = threadIdx.x;
     if (t == 0) sm.fail = (bs.nb > MAXBND) ? 1 : 0;
     __syncthreads();
-    if (t == 0 && bs.nb <= MAXBND) {
-        uint64_t s = cin;
-        sm.seg_start[0] = s;
-        for (int k = 0; k < bs.nb; k++) {
-            const uint64_t e = pure_step(sm.bnd_excl[k], s);
-            sm.bnd_ent[k] = e;
+    // Boundary walk by wave 0: lane k holds boundary k's record in registers; the exact state is handed from lane
+    // to lane with v_readlane, so a step costs one record evaluation and no memory round trip.
+    if (t < 64 && bs.nb <= MAXBND) {
+        const int lane = t, nb = bs.nb;
+        Rec rec = rec_identity(0);
+        Pure ex; ex.d0 = 0; ex.d1 = 0;
+        if (lane < nb) { rec = sm.bnd_rec[lane]; ex = sm.bnd_excl[lane]; }
+        uint64_t s = cin, my_ent = 0, my_out = 0;
+        for (int j = 0; j < nb; j++) {
+            const uint64_t e = pure_step(ex, s);
             bool ok = true;
-            uint64_t o = rec_step(sm.bnd_rec[k], e, ok);
-            if (!ok) { const long long j0 = b0 + (long long)sm.bnd_lane[k] * EL; o = literal_run<MODE>(w, nw, total, j0, j0 + EL, e); }
-            s = o;
-            sm.seg_start[k + 1] = s;
+            uint64_t o = rec_step(rec, e, ok);
+            if (lane == j && !ok) {                      // HARD leaf / window miss: its 8 terms literally, from LDS
+                double c = b2d(e);
+#pragma unroll
+                for (int q = 0; q < EL; q++) c = c + sm.bnd_terms[j][q];
+                o = d2b(c);
+            }
+            if (lane == j) { my_ent = e; my_out = o; }
+            const int olo = __builtin_amdgcn_readlane((int)(uint32_t)o, j), ohi = __builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), j);
+            s = ((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo;
         }
+        if (lane == 0) sm.seg_start[0] = cin;
+        if (lane < nb) { sm.bnd_ent[lane] = my_ent; sm.seg_start[lane + 1] = my_out; }
     }
     __syncthreads();
     if (sm.fail) return false;
@@ -724,8 +742,13 @@ __device__ __forceinline__ Rec pure_to_rec(const Pure& p, uint64_t base, long lo
 // into weights  w = exp(lw - max) / sum  (R/particle_filter_core.R:205-207), writes them, and derives
 // the approximate block prefixes from the log-sum-exp partials instead of a separate pass.
 struct FromLw {
-    const double* lw; double* w_out; const double* pm; const double* ps; int nb;
-    double* bsq; double* ain_out; int check_degenerate;
+    const double* lw; double* w_out; const double* pm; const double* ps; const double* pq; int nb;
+    double* ain_out;
+    // per-observation bookkeeping that only needs the partials (R/particle_filter_core.R:189-218): every block
+    // derives the same numbers; block 0 records them
+    int plan;                 // PLAN_PF / PLAN_AUX
+    long long N; int obs_i; int resample_algorithm; double threshold;
+    double* ess_out; double* llh_out; int* resampled_out;
 };
 
 template <int MODE, bool FROM_LW>
@@ -733,15 +756,20 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
                                               int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
                                               FromLw f)
 {
-    if (st->dead || st->flags) return;
-    if (!FROM_LW && !st->do_resample) return;
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT];
     const int t = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * EB;
+    // run-state words and this lane's terms are fetched together (one memory round trip, not two)
+    const int s_dead = st->dead, s_do = st->do_resample, dbg = st->debug_stop;
+    const uint32_t s_flags = st->flags;
     const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
-    const int dbg = st->debug_stop;
-    const bool stamper = (t == 0 && blockIdx.x == 100);
+    double vraw[EL];
+    if (!FROM_LW) load_terms<MODE_W>(w, nw, 1.0, b0 + (long long)t * EL, vraw);
+    const double a_in_pre = FROM_LW ? 0.0 : ain[blockIdx.x];
+    if (s_dead || s_flags) return;
+    if (!FROM_LW && !s_do) return;
+    const bool stamper = (t == 0 && blockIdx.x == (gridDim.x > 100 ? 100u : 0u));
     BSSM_STAMP(st, dbg, 2, 0, stamper);
     double v[EL];
     double a_in;
@@ -749,17 +777,52 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
         // global (max, sum exp) from the per-block partials, and -- from the same numbers -- the approximate
         // exclusive block prefixes of w:  sum_b w = ps[b] exp(pm[b] - M) / S
         __shared__ double es[MAXB];
+        // issue this thread's log-weight loads first: their latency hides under the reductions below
+        const long long j0 = b0 + (long long)t * EL;
+        double l8[EL];
+        if (j0 + EL <= nw) {
+            const double2* p2 = reinterpret_cast<const double2*>(f.lw + j0);
+#pragma unroll
+            for (int k = 0; k < EL / 2; k++) { const double2 q2 = p2[k]; l8[2 * k] = q2.x; l8[2 * k + 1] = q2.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EL; k++) l8[k] = (j0 + k < nw) ? f.lw[j0 + k] : -INFINITY;
+        }
         double m = -INFINITY;
         for (int i = t; i < f.nb; i += NT) m = fmax(m, f.pm[i]);
         const double M = block_max(m, sm.sh4);
-        if (f.check_degenerate && M < -1e8) return;          // degenerate: the resolve/plan step marks the run dead (:189)
-        double se = 0.0;
+        const bool degenerate = (f.plan == PLAN_PF) && (M < -1e8);       // all(log_weights < -1e8)  (:189-202)
+        if (degenerate) {
+            if (blockIdx.x == 0 && t == 0) {
+                st->loglike = -INFINITY; f.llh_out[f.obs_i - 1] = -INFINITY; st->dead = f.obs_i; st->do_resample = 0;
+            }
+            return;
+        }
+        double se = 0.0, sq = 0.0;
         for (int i = t; i < MAXB; i += NT) {
             double x = 0.0;
-            if (i < f.nb) { const double mb = f.pm[i]; x = (mb > -INFINITY) ? f.ps[i] * exp(mb - M) : 0.0; }
+            if (i < f.nb) {
+                const double mb = f.pm[i];
+                if (mb > -INFINITY) { const double ex = exp(mb - M); x = f.ps[i] * ex; sq += f.pq[i] * ex * ex; }
+            }
             es[i] = x; se += x;
         }
         const double S = block_sum(se, sm.sh4);              // (block_sum syncs: es[] is complete)
+        sq = block_sum(sq, sm.sh4);
+        int doit = 1;
+        if (f.plan == PLAN_PF) {
+            const double ess = 1.0 / (sq / (S * S));                                          // :211
+            doit = (f.resample_algorithm == 0) ? 0 : (f.resample_algorithm == 1) ? 1 : (ess < f.threshold);   // :214-218
+            if (blockIdx.x == 0 && t == 0) {
+                const double ll = st->loglike + (M + log(S) - log((double)f.N));              // :208
+                st->loglike = ll; f.llh_out[f.obs_i - 1] = ll;                                // :209
+                st->do_resample = doit;
+                f.ess_out[f.obs_i] = doit ? (double)f.N : ess;                                // :212,:223
+                if (f.resampled_out) f.resampled_out[f.obs_i - 1] = doit;
+                st->ess = ess; st->lse_max = M; st->lse_sum = S;
+                if (doit) { st->cur_call = st->res_calls; st->res_calls += 1; }
+            }
+        } else if (blockIdx.x == 0 && t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
         double ts0 = 0.0;
 #pragma unroll
         for (int k = 0; k < MAXB / NT; k++) ts0 += es[t * (MAXB / NT) + k];
@@ -773,25 +836,32 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
         }
         __syncthreads();
         a_in = sm.bcast;
-        const long long j0 = b0 + (long long)t * EL;
-        double s2 = 0.0, s1 = 0.0;
+        BSSM_STAMP(st, dbg, 2, 8, stamper);
+        double s1 = 0.0;
 #pragma unroll
         for (int k = 0; k < EL; k++) {
-            const double l = (j0 + k < nw) ? f.lw[j0 + k] : -INFINITY;
-            const double x = (j0 + k < nw) ? exp(l - M) / S : 0.0;
-            v[k] = x; s1 += x; s2 += x * x;
-            if (j0 + k < nw) f.w_out[j0 + k] = x;
+            const double x = (j0 + k < nw) ? exp(l8[k] - M) / S : 0.0;                         // :205-207
+            v[k] = x; s1 += x;
         }
-        s2 = block_sum(s2, sm.sh4);
+        if (j0 + EL <= nw) {
+            double2* p2 = reinterpret_cast<double2*>(f.w_out + j0);
+#pragma unroll
+            for (int k = 0; k < EL / 2; k++) { double2 q2; q2.x = v[2 * k]; q2.y = v[2 * k + 1]; p2[k] = q2; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EL; k++) if (j0 + k < nw) f.w_out[j0 + k] = v[k];
+        }
+        if (!doit) return;                                   // SIS / SISAR without a resample: weights are all that is needed
         s1 = block_sum(s1, sm.sh4);
-        if (t == 0) {
-            f.bsq[blockIdx.x] = s2;
-            if (!isfinite(s1)) atomicOr(&st->flags, FLAG_NONFINITE);   // NaN/Inf log-weights: the scan stands down
+        if (!isfinite(s1)) {                                 // NaN/Inf log-weights: the scan stands down
+            if (t == 0) atomicOr(&st->flags, FLAG_NONFINITE);
+            return;
         }
-        if (!isfinite(s1)) return;
+        BSSM_STAMP(st, dbg, 2, 9, stamper);
     } else {
-        load_terms<MODE>(w, nw, total, b0 + (long long)t * EL, v);
-        a_in = ain[blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < EL; k++) v[k] = (MODE == MODE_P) ? vraw[k] / total : vraw[k];   // prob = weights / total (src/resampling.cpp:24,51)
+        a_in = a_in_pre;
     }
     if (dbg == 1) { if (v[0] + v[7] == -1.0) tin[t] = 1; return; }
     BSSM_STAMP(st, dbg, 2, 1, stamper && v[0] >= 0.0);
@@ -953,64 +1023,30 @@ __device__ uint64_t block_out_exact(const BlockRec& br, const SideList* __restri
 constexpr int NTR = 1024;        // threads of the single resolve workgroup (16 waves)
 constexpr int SIDE_CACHE = 12;   // side entries staged in LDS for the boundary walk
 
-// In the filter the MODE_W resolve also does the per-observation bookkeeping that needs every block's
-// partials: log-likelihood increment, ESS, resample decision (R/particle_filter_core.R:189-218).
-struct PlanArgs {
-    int plan;                 // PLAN_RESAMPLE_ONLY: nothing to do here
-    const double* pm; const double* ps; const double* bsq; int nb;
-    long long N; int obs_i; int resample_algorithm; double threshold;
-    double* ess_out; double* llh_out; int* resampled_out;
-};
-
 template <int MODE>
 __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, long long nw, int B,
                                                  const BlockRec* __restrict__ brec, const SideList* __restrict__ side,
                                                  uint64_t* __restrict__ cin,
-                                                 const double* __restrict__ ain_w, double* __restrict__ ain_p, DevState* st,
-                                                 PlanArgs pa)
+                                                 const double* __restrict__ ain_w, double* __restrict__ ain_p, DevState* st)
 {
-    if (st->dead || st->flags) return;
     extern __shared__ __attribute__((aligned(16))) char smraw[];
     BlockRec* br = reinterpret_cast<BlockRec*>(smraw);
     __shared__ SegSmem sm;
     __shared__ uint64_t final_state;
     __shared__ __attribute__((aligned(16))) SideEntry sideC[64];
     const int t = threadIdx.x;
-    const int dbg0 = st->debug_stop;
+    // run-state words are fetched together with the block records (checked after the staging barrier)
+    const int s_dead = st->dead, s_do = st->do_resample, dbg0 = st->debug_stop;
+    const uint32_t s_flags = st->flags;
+    const uint64_t s_total = st->total_bits;
     BSSM_STAMP(st, dbg0, MODE, 0, t == 0);
-    if (MODE == MODE_W && pa.plan != PLAN_RESAMPLE_ONLY) {
-        __shared__ int go;
-        if (pa.plan == PLAN_PF) {
-            double M, S;
-            reduce_lse_partials<NTR / 64>(pa.pm, pa.ps, pa.nb, sm.sh4, M, S);
-            double q = 0.0;
-            for (int i = t; i < pa.nb; i += NTR) q += pa.bsq[i];
-            if (M < -1e8) q = 0.0;
-            q = block_sum_n<NTR / 64>(q, sm.sh4);
-            if (t == 0) {
-                if (M < -1e8) {                  // all(log_weights < -1e8)  (:189-202)
-                    st->loglike = -INFINITY; pa.llh_out[pa.obs_i - 1] = -INFINITY; st->dead = pa.obs_i; st->do_resample = 0;
-                    go = 0;
-                } else {
-                    const double ll = st->loglike + (M + log(S) - log((double)pa.N));   // :208
-                    st->loglike = ll; pa.llh_out[pa.obs_i - 1] = ll;                     // :209
-                    const double ess = 1.0 / q;                                          // :211
-                    const int doit = (pa.resample_algorithm == 0) ? 0 : (pa.resample_algorithm == 1) ? 1 : (ess < pa.threshold);  // :214-218
-                    st->do_resample = doit;
-                    pa.ess_out[pa.obs_i] = doit ? (double)pa.N : ess;                    // :212,:223
-                    if (pa.resampled_out) pa.resampled_out[pa.obs_i - 1] = doit;
-                    st->ess = ess; st->lse_max = M; st->lse_sum = S;
-                    if (doit) { st->cur_call = st->res_calls; st->res_calls += 1; }
-                    go = doit;
-                }
-            }
-        } else if (t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; go = 1; }
-        __syncthreads();
-        if (!go) return;
-    } else {
-        if (!st->do_resample) return;
-    }
     BSSM_STAMP(st, dbg0, MODE, 1, t == 0);
+    // The last block nearly always carries one side entry (the lanes next to cum == 1.0 are never PURE): fetch it
+    // now, together with the block records, so the walk does not wait for a dependent global load later.
+    if (t >= NTR - (int)(sizeof(SideEntry) / 16)) {
+        const int q = t - (NTR - (int)(sizeof(SideEntry) / 16));
+        reinterpret_cast<uint4*>(&sideC[63])[q] = reinterpret_cast<const uint4*>(&side[B - 1].e[0])[q];
+    }
     {   // stage the block records in LDS (16-byte pieces)
         const uint4* src = reinterpret_cast<const uint4*>(brec);
         uint4* dst = reinterpret_cast<uint4*>(smraw);
@@ -1019,10 +1055,11 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     }
     if (t == 0) sm.fail = 0;
     __syncthreads();
-    const int dbg = st->debug_stop;
+    if (s_dead || s_flags || !s_do) return;
+    const int dbg = dbg0;
     BSSM_STAMP(st, dbg0, MODE, 2, t == 0);
     if (dbg == 11) return;
-    const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
+    const double total = (MODE == MODE_P) ? b2d(s_total) : 1.0;
     const int CB = (B + NTR - 1) / NTR;                // blocks per thread (1 or 2)
     const int c0 = t * CB, c1 = (c0 + CB < B) ? c0 + CB : B;
     // chunk record: PURE composite + validity window relative to the first block's base
@@ -1073,7 +1110,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
         if (bidx >= 0) {
             pr = br[bidx].prefix; nside = br[bidx].nside;
             slow = (nside > 1) || (br[bidx].tail_from < NT);
-            if (nside == 1 && !slow && fits) {   // stage the single side entry in LDS (read only when it is this lane's turn)
+            if (nside == 1 && !slow && fits && !(bidx == B - 1 && lane < 63)) {   // (the last block's entry is already in slot 63)
                 const uint4* sp = reinterpret_cast<const uint4*>(&side[bidx].e[0]);
                 uint4* dp = reinterpret_cast<uint4*>(&sideC[lane]);
 #pragma unroll
@@ -1083,32 +1120,37 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
         if (!fits) { if (lane == 0) sm.fail = 1; }
         else {
             uint64_t s = 0, my_in = 0, my_out = 0;
+            const bool special = (bidx >= 0) && (slow || nside == 1);
             for (int j = 0; j < nent; j++) {
                 const uint64_t e = pure_step(ex, s);
                 uint64_t o = e;
                 bool ok = true;
-                if (bidx >= 0 && !slow) o = rec_step(pr, e, ok);
-                if (lane == j && bidx >= 0 && !slow && ok && nside == 1) {
-                    const SideEntry& se = sideC[lane];
-                    bool ok2 = true;
-                    uint64_t o2 = rec_step(se.leaf, o, ok2);
-                    if (!ok2) {                              // HARD leaf: its 8 terms literally (kept in the entry)
-                        double c = b2d(o);
+                if (bidx >= 0) o = rec_step(pr, e, ok);
+                if (lane == j && (special || !ok)) {             // rare: side entry / tails / window miss
+                    bool done = false;
+                    if (!slow && ok && nside == 1) {
+                        const SideEntry& se = sideC[(bidx == B - 1) ? 63 : lane];
+                        bool ok2 = true;
+                        uint64_t o2 = rec_step(se.leaf, o, ok2);
+                        if (!ok2) {                          // HARD leaf: its 8 terms literally (kept in the entry)
+                            double c = b2d(o);
 #pragma unroll
-                        for (int q = 0; q < EL; q++) c = c + se.terms[q];
-                        o2 = d2b(c);
+                            for (int q = 0; q < EL; q++) c = c + se.terms[q];
+                            o2 = d2b(c);
+                        }
+                        done = true;
+                        if (se.pad) {
+                            const int64_t diff = (int64_t)(o2 - se.post_base);
+                            if (diff < (int64_t)se.lo || diff > (int64_t)se.hi) done = false;
+                            else { Pure pp; pp.d0 = se.d0; pp.d1 = se.d1; o2 = pure_step(pp, o2); }
+                        }
+                        if (done) o = o2;
                     }
-                    o = o2;
-                    if (se.pad) {
-                        const int64_t diff = (int64_t)(o - se.post_base);
-                        if (diff < (int64_t)se.lo || diff > (int64_t)se.hi) ok = false;
-                        else { Pure pp; pp.d0 = se.d0; pp.d1 = se.d1; o = pure_step(pp, o); }
-                    }
+                    if (!done) o = block_out_exact<MODE>(br[bidx], side, w, nw, total, bidx, e, lit);   // the general (slower) routine
                 }
-                if (lane == j && bidx >= 0 && (slow || !ok))     // anything unusual: the general (slower) routine
-                    o = block_out_exact<MODE>(br[bidx], side, w, nw, total, bidx, e, lit);
                 if (lane == j) { my_in = e; my_out = o; }
-                const int olo = __shfl((int)(uint32_t)o, j, 64), ohi = __shfl((int)(uint32_t)(o >> 32), j, 64);
+                // hand lane j's result to everyone (j is wave-uniform: v_readlane, no LDS round trip)
+                const int olo = __builtin_amdgcn_readlane((int)(uint32_t)o, j), ohi = __builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), j);
                 s = ((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo;
             }
             if (lane == 0) sm.seg_start[0] = 0;
@@ -1190,7 +1232,6 @@ struct ApplyArgs {
 template <int KIND>
 __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
 {
-    if (st->dead || !st->do_resample || st->flags) return;
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT];
     __shared__ int Tl[EB];
@@ -1199,21 +1240,26 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     __shared__ unsigned short own[OWN_CAP];
     const int t = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * EB;
+    // run-state words and this lane's terms are fetched together (one memory round trip, not two)
+    const int s_dead = st->dead, s_do = st->do_resample, call = st->cur_call, dbg = st->debug_stop;
+    const uint32_t s_flags = st->flags;
     const double total = b2d(st->total_bits);
-    const int call = st->cur_call;
-    const int dbg = st->debug_stop;
-    const bool stamper = (t == 0 && blockIdx.x == 100);
-    BSSM_STAMP(st, dbg, 3, 0, stamper);
     double v[EL];
-    load_terms<MODE_P>(a.w, a.nw, total, b0 + (long long)t * EL, v);
+    load_terms<MODE_W>(a.w, a.nw, 1.0, b0 + (long long)t * EL, v);
+    const double a_in_p = a.ain_p[blockIdx.x];
+    const uint64_t cinb = a.cin[blockIdx.x];
+    if (s_dead || !s_do || s_flags) return;
+    const bool stamper = (t == 0 && blockIdx.x == (gridDim.x > 100 ? 100u : 0u));
+    BSSM_STAMP(st, dbg, 3, 0, stamper);
+#pragma unroll
+    for (int k = 0; k < EL; k++) v[k] = v[k] / total;                  // prob = weights / total (src/resampling.cpp:24,51)
     if (dbg == 1) { if (v[0] + v[7] == -1.0) Tl[t] = 1; return; }
     BSSM_STAMP(st, dbg, 3, 1, stamper && v[0] >= 0.0);
     BlockScan bs;
-    block_scan<MODE_P>(sm, v, a.ain_p[blockIdx.x], a.lim, bs);
+    block_scan<MODE_P>(sm, v, a_in_p, a.lim, bs);
     __syncthreads();
     BSSM_STAMP(st, dbg, 3, 2, stamper);
     if (dbg == 2) { if (bs.exc.d0 == -12345) Tl[t] = 1; return; }
-    const uint64_t cinb = a.cin[blockIdx.x];
     uint64_t ent;
     const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
     if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
