@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--resample-fn", default="systematic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-pmmh", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +165,23 @@ def main():
         else:
             out["roofline"] = {"bound": "hbm", "kernel": "whole sweep", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None}
+        if not args.no_pmmh:
+            # second half of BASELINE's metric: PMMH iterations/s (one iteration = one filter run + host MH step),
+            # same model/N/T, theta = (phi, sigma_x, sigma_y), priors N(0,1)/Exp(1)/Exp(1), transforms identity/log/log
+            # (tests/testthat/test-pmmh.R:93-106,421-425).  Un-timed for `value`; reported alongside.
+            from bayesssm_amd.pmmh import run_chain_device, prior_normal, prior_exponential
+            iters = max(3, min(args.steps, 6))
+            t1 = time.perf_counter()
+            ch = run_chain_device(pf_wrapper=b.bootstrap_filter, y=ys, m=iters + 1, model="lg", n_params=3,
+                                  init_theta=list(theta), proposal_cov=np.diag([1e-4, 1e-4, 1e-4]),
+                                  transform=["identity", "log", "log"],
+                                  priors=[prior_normal(0, 1), prior_exponential(1), prior_exponential(1)],
+                                  num_particles=N, seed=1405, chain_index=0, resample_algorithm="SISR",
+                                  resample_fn=args.resample_fn, ctx=ctx)
+            dt1 = time.perf_counter() - t1
+            out["pmmh"] = {"iters_per_sec_per_gpu": (iters + 1) / dt1, "iterations_timed": iters + 1,
+                           "accepted": ch["accepted"], "note": "1 chain on this GPU; chains shard one per GPU "
+                           "(no data-path collective), so N GPUs run N chains at this rate each"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ys, theta, rank)
     if dist is not None:
