@@ -10,12 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbayesssm_amd.so")
 
 OK, ERR_NEGATIVE, ERR_ZERO_SUM, ERR_LENGTH, ERR_ARG, ERR_HIP, ERR_CAPACITY = range(7)
-MODEL = {"lg": 0, "ar1sin": 1}
+MODEL = {"lg": 0, "ar1sin": 1, "sir": 2}
 ALGORITHM = {"BPF": 0, "APF": 1}
 RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
 RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2}
 TRANSFORM = {"identity": 0, "log": 1, "logit": 2}
-PRIOR = {"normal": 0, "exponential": 1, "uniform": 2, "flat": 3}
+PRIOR = {"normal": 0, "exponential": 1, "uniform": 2, "flat": 3, "halfnormal": 4}
 
 
 class BssmError(RuntimeError):
@@ -130,6 +130,7 @@ class Context:
         self._h = h
         self.device = device
         self.max_particles = max_particles
+        self.max_dim = max_dim
 
     @property
     def handle(self):
@@ -164,15 +165,17 @@ class Context:
 _default_ctx = {}
 
 
-def default_context(min_particles=1, device=None):
-    """Lazily created per-device context, grown when a larger filter is requested."""
+def default_context(min_particles=1, device=None, dim=1):
+    """Lazily created per-device context, grown when a larger filter (or state dimension) is requested."""
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0")) % max(load().bssm_device_count(), 1)
     ctx = _default_ctx.get(device)
-    if ctx is None or ctx.max_particles < min_particles:
+    if ctx is None or ctx.max_particles < min_particles or ctx.max_dim < dim:
+        old_dim = ctx.max_dim if ctx is not None else 1
+        old_cap = ctx.max_particles if ctx is not None else 0
         if ctx is not None:
             ctx.close()
-        cap = max(1 << 16, 1 << (int(min_particles) - 1).bit_length())
-        ctx = Context(device, cap, 1)
+        cap = max(1 << 16, 1 << (int(max(min_particles, old_cap)) - 1).bit_length())
+        ctx = Context(device, cap, max(dim, old_dim))
         _default_ctx[device] = ctx
     return ctx

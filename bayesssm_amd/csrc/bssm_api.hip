@@ -425,11 +425,24 @@ static void launch_step(bssm_ctx* c, bool trans, int weight, bool subaux, double
 #undef STEP_ARGS
 }
 
+static void launch_step_sir(bssm_ctx* c, bool trans, int weight, bool subaux, double* x, long long N, int B,
+                            const ModelPar& par, double y, const NoiseSrc& ns)
+{
+#define SIR_ARGS(LW) x, x, LW, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq
+    if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step_sir<trans+weight>", (k_step_sir<true, 1, false>), B, NTS, 0, SIR_ARGS(c->lw));
+    else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step_sir<trans+weight-aux>", (k_step_sir<true, 1, true>), B, NTS, 0, SIR_ARGS(c->lw));
+    else if (trans && weight == 0) LAUNCH(c, "k_step_sir<trans>", (k_step_sir<true, 0, false>), B, NTS, 0, SIR_ARGS(c->lw));
+    else if (!trans && weight == 2) LAUNCH(c, "k_step_sir<aux-weight>", (k_step_sir<false, 2, false>), B, NTS, 0, SIR_ARGS(c->auxlw));
+    else if (!trans && weight == 1) LAUNCH(c, "k_step_sir<weight>", (k_step_sir<false, 1, false>), B, NTS, 0, SIR_ARGS(c->lw));
+#undef SIR_ARGS
+}
+
 static void launch_step_model(bssm_ctx* c, int model, bool trans, int weight, bool subaux, double* x, long long N, int B,
                               const ModelPar& par, double y, const NoiseSrc& ns)
 {
     if (model == BSSM_MODEL_LG) launch_step<0>(c, trans, weight, subaux, x, N, B, par, y, ns);
-    else launch_step<1>(c, trans, weight, subaux, x, N, B, par, y, ns);
+    else if (model == BSSM_MODEL_AR1SIN) launch_step<1>(c, trans, weight, subaux, x, N, B, par, y, ns);
+    else launch_step_sir(c, trans, weight, subaux, x, N, B, par, y, ns);
 }
 
 extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* res)
@@ -440,11 +453,15 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     if (N <= 0) ARGFAIL("num_particles must be a positive count");                    // assert_count(..., positive = TRUE) :33
     if (T < 0) ARGFAIL("bssm_pf_run: T must be >= 0");
     if (N > c->cap) { g_err = "bssm_pf_run: num_particles exceeds context capacity"; return BSSM_ERR_CAPACITY; }
-    if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN) ARGFAIL("bssm_pf_run: unknown model");
+    if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN && cfg->model != BSSM_MODEL_SIR) ARGFAIL("bssm_pf_run: unknown model");
+    const bool sir = cfg->model == BSSM_MODEL_SIR;
+    if (sir && (cfg->z_init || cfg->z_trans)) ARGFAIL("bssm_pf_run: the SIR model draws a data-dependent number of variates; injected z_* are not supported");
+    if (sir && cfg->n_theta < 5) ARGFAIL("bssm_pf_run: SIR theta must hold (lambda, gamma, n_total, s0, i0)");
+    if (sir && c->max_dim < 2) { g_err = "bssm_pf_run: the SIR model needs a context created with max_dim = 2"; return BSSM_ERR_CAPACITY; }
     if (cfg->algorithm != BSSM_BPF && cfg->algorithm != BSSM_APF) ARGFAIL("bssm_pf_run: unknown algorithm");
     if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run: unknown resample_algorithm");
     if (cfg->resample_fn < 0 || cfg->resample_fn > 2) ARGFAIL("bssm_pf_run: unknown resample_fn");
-    if (!cfg->theta || cfg->n_theta < 3) ARGFAIL("bssm_pf_run: theta must hold (phi, sigma_x, sigma_y)");
+    if (!cfg->theta || cfg->n_theta < 3) ARGFAIL("bssm_pf_run: theta must hold (phi, sigma_x, sigma_y) or (lambda, gamma, n_total, s0, i0)");
     if (T > 0 && !cfg->y) ARGFAIL("bssm_pf_run: y is NULL");
     if (!res->state_est || !res->ess || !res->loglike || (T > 0 && !res->loglike_history)) ARGFAIL("bssm_pf_run: result buffers missing");
     for (int i = 0; i < T; i++) if (!isfinite(cfg->y[i])) ARGFAIL("Assertion on 'y' failed: Contains missing values");  // assert_numeric(y, any.missing = FALSE) :69
@@ -453,7 +470,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         for (int i = 0; i < T; i++) { if (cfg->obs_times[i] < prev) ARGFAIL("Assertion on 'obs_times' failed: Must be sorted and >= 1"); prev = cfg->obs_times[i]; }
     }
     HIPCHK(hipSetDevice(c->device));
-    const int dim = 1;
+    const int dim = sir ? 2 : 1;
     const int B = (int)((N + EB - 1) / EB);
     const bool apf = cfg->algorithm == BSSM_APF;
     const double dN = (double)N;
@@ -487,7 +504,9 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     HIPCHK(hipMemsetAsync(d_resampled, 0, (size_t)(T + 1) * 4, c->stream));
     if (d_anc) HIPCHK(hipMemsetAsync(d_anc, 0, (size_t)std::max(max_res, 1) * N * 4, c->stream));
 
-    ModelPar par; par.phi = cfg->theta[0]; par.sx = cfg->theta[1]; par.sy = cfg->theta[2]; par.log_sy = log(cfg->theta[2]);
+    ModelPar par; memset(&par, 0, sizeof(par));
+    par.phi = cfg->theta[0]; par.sx = cfg->theta[1]; par.sy = cfg->theta[2]; par.log_sy = log(cfg->theta[2]);
+    if (sir) { par.n_total = cfg->theta[2]; par.s0 = cfg->theta[3]; par.i0 = cfg->theta[4]; }
     const PhiloxKey key = make_key(cfg->seed, cfg->stream);
     double* X0 = c->x0; double* X1 = c->x1;
     double* separt = (double*)d_separt;
@@ -497,7 +516,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     if (g_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, g_debug_stop);
     {   // t = 0  (:76-116)
         NoiseSrc ns; ns.arr = (const double*)d_zi; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
-        LAUNCH(c, "k_init", k_init, B, NT, 0, X0, N, ns, separt);
+        LAUNCH(c, "k_init", k_init, B, NT, 0, X0, N, ns, separt, cfg->model, par);
         if (cfg->return_particles) {
             // weights = rep(1/N, N): do_resample is 0 after reset, so seed row 0 from a constant fill
             std::vector<double> w0((size_t)N, 1.0 / dN);
@@ -512,6 +531,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         const int gap = ot - prev_t;                                                      // :124
         prev_t = ot;
         const double yi = cfg->y[i - 1];
+        if (sir) par.lgy = lgamma(yi + 1.0);
         auto noise = [&](int k) { NoiseSrc ns; ns.arr = d_zt ? (const double*)d_zt + (size_t)k * N : nullptr; ns.key = key; ns.purpose = DRAW_TRANS; ns.call = (uint32_t)k; return ns; };
         ResampleLaunch r;
         r.d_w = c->w; r.nw = N; r.n = (int)N; r.kind = cfg->resample_fn; r.d_u = (const double*)d_ur; r.u_stride = u_stride; r.key = key;
@@ -534,7 +554,8 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
             // obs_times repeats a time: no transition, weights on the current particles
             NoiseSrc ns = noise(0);
             if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st);
-            else LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st);
+            else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st);
+            else launch_step_sir(c, false, 1, false, X0, N, B, par, yi, ns);
         }
         double* se_row = separt + (size_t)i * B * dim;
         // normalise (:204-207) + loglik/ESS/decision (:208-218) + resample (:220-224), fused into the scan kernels
@@ -608,6 +629,8 @@ static double log_prior(int kind, double a, double b, double x)
         case BSSM_PRIOR_NORMAL: { const double z = (x - a) / b; return -(BSSM_LN_SQRT_2PI + 0.5 * z * z + log(b)); }   // dnorm(log=TRUE)
         case BSSM_PRIOR_EXP: return (x < 0) ? -INFINITY : (log(a) - a * x);                                         // dexp(rate, log=TRUE)
         case BSSM_PRIOR_UNIFORM: return (x >= a && x <= b) ? -log(b - a) : -INFINITY;                               // dunif(log=TRUE)
+        case BSSM_PRIOR_HALFNORMAL: { if (x < 0) return -INFINITY; const double z = x / a;                          // extraDistr::dhnorm(x, sigma = a, log = TRUE)
+                                      return log(2.0) - (BSSM_LN_SQRT_2PI + 0.5 * z * z + log(a)); }
         default: return 0.0;
     }
 }
@@ -642,16 +665,21 @@ extern "C" int bssm_pmmh_chain(bssm_ctx* c, const bssm_pmmh_config* cfg, bssm_pm
     }
     const PhiloxKey ckey = make_key(cfg->seed, 0x50000000ull + (unsigned long long)cfg->chain_index);
     std::vector<double> cur(cfg->init_theta, cfg->init_theta + p), prop(p), z(p), ztr(p), lp_prop(p);
-    std::vector<double> se_cur((size_t)T + 1), se_prop((size_t)T + 1), ess((size_t)T + 1), llh((size_t)std::max(T, 1));
+    const int dim = (cfg->pf.model == BSSM_MODEL_SIR) ? 2 : 1;
+    const int n_full = std::max(cfg->pf.n_theta, p);            // sampled parameters first, then fixed model constants
+    std::vector<double> th_full((size_t)n_full, 0.0);
+    for (int j = p; j < n_full; j++) th_full[j] = cfg->pf.theta ? cfg->pf.theta[j] : 0.0;
+    std::vector<double> se_cur(((size_t)T + 1) * dim), se_prop(((size_t)T + 1) * dim), ess((size_t)T + 1), llh((size_t)std::max(T, 1));
     double ll = 0, ms = 0, ms_total = 0;
     int ers = 0, nres = 0;
     bssm_pf_config pf = cfg->pf;
-    pf.n_theta = p; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
+    pf.n_theta = n_full; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
     pf.seed = cfg->seed;
     bssm_pf_result pr; memset(&pr, 0, sizeof(pr));
     pr.scan_stats = nullptr; pr.ess = ess.data(); pr.loglike_history = llh.data(); pr.loglike = &ll; pr.early_return_step = &ers; pr.n_res_calls = &nres; pr.device_ms = &ms;
     auto run_pf = [&](const std::vector<double>& th, std::vector<double>& se, unsigned iter) -> int {
-        pf.theta = th.data(); pr.state_est = se.data();
+        for (int j = 0; j < p; j++) th_full[j] = th[j];
+        pf.theta = th_full.data(); pr.state_est = se.data();
         pf.stream = ((unsigned long long)cfg->chain_index << 32) | iter;
         const int rc = bssm_pf_run(c, &pf, &pr);
         ms_total += ms;
@@ -664,7 +692,7 @@ extern "C" int bssm_pmmh_chain(bssm_ctx* c, const bssm_pmmh_config* cfg, bssm_pm
     auto store = [&](int i) {
         for (int j = 0; j < p; j++) res->theta_chain[(size_t)i * p + j] = cur[j];
         if (res->loglike_chain) res->loglike_chain[i] = cur_ll;
-        if (res->state_est_chain) memcpy(res->state_est_chain + (size_t)i * (T + 1), se_cur.data(), sizeof(double) * (T + 1));
+        if (res->state_est_chain) memcpy(res->state_est_chain + (size_t)i * (T + 1) * dim, se_cur.data(), sizeof(double) * (T + 1) * dim);
     };
     store(0);
     for (int i = 1; i < m; i++) {                                                        // for (i in 2:m)  R/pmmh.R:422

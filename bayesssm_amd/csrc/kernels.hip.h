@@ -219,7 +219,7 @@ __device__ void reduce_lse_partials(const double* pm, const double* ps, int nb, 
 // Built-in models: the reference's user closures restated for the device.
 // theta = (phi, sigma_x, sigma_y).
 // ---------------------------------------------------------------------------
-struct ModelPar { double phi, sx, sy, log_sy; };
+struct ModelPar { double phi, sx, sy, log_sy; double n_total, s0, i0, lgy; };   // SIR: phi = lambda, sx = gamma, lgy = lgamma(y+1)
 
 // rnorm(n, mu, sd) = mu + sd * z   (R nmath/rnorm.c)
 __device__ __forceinline__ double r_rnorm(double mu, double sd, double z) { return mu + sd * z; }
@@ -244,6 +244,47 @@ template <> struct Model<1> {   // BSSM_MODEL_AR1SIN   README.md:137-146
     __device__ static double forecast(double x, const ModelPar& p) { return p.phi * x + sin(x); }
 };
 
+// Stochastic SIR (vignettes/articles/stochastic-sir-model.Rmd:152-176, 285-310): state (s, i), one Gillespie day
+// per transition, y ~ Poisson(i).  theta = (lambda, gamma, n_total, s0, i0).
+struct Sir {
+    // epidemic_step (:152-176) for ONE particle; draws keyed (particle, event) inside call `call`
+    __device__ static void transition(double& s, double& i, const ModelPar& p, PhiloxKey key, uint32_t call, uint32_t particle)
+    {
+        if (i == 0.0) return;                                   // transition_fn: if (i == 0) return(c(s, i))  (:296-298)
+        double t = 0.0;
+        uint32_t ev = 0;
+        while (t < 1.0 && i > 0.0 && ev < (1u << 20)) {
+            const double rate_infection = (p.phi / p.n_total) * s * i;
+            const double rate_removal = p.sx * i;
+            const double rate_total = rate_infection + rate_removal;
+            if (rate_total <= 0.0) break;
+            u32x4 c; c.x = particle; c.y = call; c.z = DRAW_TRANS | (ev << 8); c.w = key.stream;
+            const u32x4 r = philox4x32_10(c, key.k0, key.k1);
+            const double dt = -log(u01_from_bits(r.x, r.y)) / rate_total;      // rexp(1, rate_total)
+            if (t + dt > 1.0) break;
+            t = t + dt;
+            if (u01_from_bits(r.z, r.w) < rate_infection / rate_total) { s = s - 1.0; i = i + 1.0; }
+            else { i = i - 1.0; }
+            ev++;
+        }
+    }
+    // dpois(y, lambda, log = TRUE) = y log(lambda) - lambda - lgamma(y + 1)   (R's dpois_raw evaluates the same
+    // quantity through stirlerr/bd0; the two agree to ~1e-14 relative)
+    __device__ static double dpois_log(double y, double lambda, double lgy)
+    {
+        if (lambda <= 0.0) return (y == 0.0 && lambda == 0.0) ? 0.0 : -INFINITY;
+        if (y == 0.0) return -lambda;
+        return y * log(lambda) - lambda - lgy;
+    }
+    __device__ static double loglik(double y, double i, const ModelPar& p) { return dpois_log(y, i, p.lgy); }
+    // APF look-ahead (this build's choice; the reference defines none for SIR): Poisson at the one-day mean of i
+    __device__ static double aux_loglik(double y, double s, double i, const ModelPar& p)
+    {
+        const double m = i + (p.phi / p.n_total) * s * i - p.sx * i;
+        return dpois_log(y, m > 0.0 ? m : 0.0, p.lgy);
+    }
+};
+
 struct NoiseSrc {
     const double* arr;     // parity mode: N draws for this call; nullptr => generator
     PhiloxKey key;
@@ -255,26 +296,33 @@ struct NoiseSrc {
 // estimate partial sums (:109)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_init(double* __restrict__ x, long long N, NoiseSrc ns,
-                                             double* __restrict__ se_part /* [nblocks] */)
+                                             double* __restrict__ se_part /* [nblocks][dim] */, int model, ModelPar par)
 {
     __shared__ double sh4[4];
     const long long base = (long long)blockIdx.x * EB;
     const double invN = 1.0 / (double)N;
-    double acc = 0.0;
+    double acc = 0.0, acc1 = 0.0;
 #pragma unroll
     for (int r = 0; r < EL / 2; r++) {
         const long long j = base + 2 * (threadIdx.x + NT * r);
         if (j < N) {
-            double z0, z1;
-            if (ns.arr) { z0 = ns.arr[j]; z1 = (j + 1 < N) ? ns.arr[j + 1] : 0.0; }
-            else normal_pair(ns.key, ns.purpose, ns.call, 0, (uint32_t)(j >> 1), z0, z1);
-            const double x0 = r_rnorm(0.0, 1.0, z0), x1 = r_rnorm(0.0, 1.0, z1);
-            x[j] = x0; acc += x0 * invN;
-            if (j + 1 < N) { x[j + 1] = x1; acc += x1 * invN; }
+            if (model == 2) {   // SIR: every particle starts at (s0, i0)  (stochastic-sir-model.Rmd:286-293)
+                x[j] = par.s0; x[N + j] = par.i0; acc += par.s0 * invN; acc1 += par.i0 * invN;
+                if (j + 1 < N) { x[j + 1] = par.s0; x[N + j + 1] = par.i0; acc += par.s0 * invN; acc1 += par.i0 * invN; }
+            } else {
+                double z0, z1;
+                if (ns.arr) { z0 = ns.arr[j]; z1 = (j + 1 < N) ? ns.arr[j + 1] : 0.0; }
+                else normal_pair(ns.key, ns.purpose, ns.call, 0, (uint32_t)(j >> 1), z0, z1);
+                const double x0 = r_rnorm(0.0, 1.0, z0), x1 = r_rnorm(0.0, 1.0, z1);
+                x[j] = x0; acc += x0 * invN;
+                if (j + 1 < N) { x[j + 1] = x1; acc += x1 * invN; }
+            }
         }
     }
+    const int dim = (model == 2) ? 2 : 1;
     acc = block_sum(acc, sh4);
-    if (threadIdx.x == 0) se_part[blockIdx.x] = acc;
+    if (dim > 1) acc1 = block_sum(acc1, sh4);
+    if (threadIdx.x == 0) { se_part[(long long)blockIdx.x * dim] = acc; if (dim > 1) se_part[(long long)blockIdx.x * dim + 1] = acc1; }
 }
 
 // ---------------------------------------------------------------------------
@@ -331,6 +379,47 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
     if (WEIGHT) {
         const double bm = block_max_n<NTS / 64>(fmax(l0, l1), sh);
         double s = 0.0, q = 0.0;                       // sum exp(l - bm) and sum exp(l - bm)^2 (the latter feeds the ESS)
+        if (bm > -INFINITY) {
+            if (l0 > -INFINITY) { const double e = exp(l0 - bm); s += e; q += e * e; }
+            if (l1 > -INFINITY) { const double e = exp(l1 - bm); s += e; q += e * e; }
+        }
+        s = block_sum_n<NTS / 64>(s, sh);
+        q = block_sum_n<NTS / 64>(q, sh);
+        if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; }
+    }
+}
+
+// SIR variant of k_step (state dimension 2, data-dependent Gillespie loop: VALU/divergence-bound, not HBM-bound)
+template <bool TRANS, int WEIGHT, bool SUBAUX>
+__global__ __launch_bounds__(NTS) void k_step_sir(const double* xin, double* xout /* may alias xin */,
+                                                  double* __restrict__ lw, const double* __restrict__ auxg,
+                                                  long long N, ModelPar par, double y, NoiseSrc ns,
+                                                  double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq)
+{
+    __shared__ double sh[NTS / 64];
+    const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
+    double l0 = -INFINITY, l1 = -INFINITY;
+    if (j < N) {
+        const bool two = (j + 1 < N);
+        double s0 = xin[j], i0 = xin[N + j];
+        double s1 = two ? xin[j + 1] : 0.0, i1 = two ? xin[N + j + 1] : 0.0;
+        if (TRANS) {
+            Sir::transition(s0, i0, par, ns.key, ns.call, (uint32_t)j);
+            if (two) Sir::transition(s1, i1, par, ns.key, ns.call, (uint32_t)(j + 1));
+            xout[j] = s0; xout[N + j] = i0;
+            if (two) { xout[j + 1] = s1; xout[N + j + 1] = i1; }
+        }
+        if (WEIGHT) {
+            if (WEIGHT == 2) { l0 = Sir::aux_loglik(y, s0, i0, par); l1 = Sir::aux_loglik(y, s1, i1, par); }
+            else { l0 = Sir::loglik(y, i0, par); l1 = Sir::loglik(y, i1, par); }
+            if (SUBAUX) { l0 = l0 - auxg[j]; if (two) l1 = l1 - auxg[j + 1]; }
+            lw[j] = l0;
+            if (two) lw[j + 1] = l1; else l1 = -INFINITY;
+        }
+    }
+    if (WEIGHT) {
+        const double bm = block_max_n<NTS / 64>(fmax(l0, l1), sh);
+        double s = 0.0, q = 0.0;
         if (bm > -INFINITY) {
             if (l0 > -INFINITY) { const double e = exp(l0 - bm); s += e; q += e * e; }
             if (l1 > -INFINITY) { const double e = exp(l1 - bm); s += e; q += e * e; }

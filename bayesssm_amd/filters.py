@@ -50,11 +50,12 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
         if ot.size != T or (T and (ot[0] < 1 or np.any(np.diff(ot) < 0))):
             raise ValueError("Assertion on 'obs_times' failed")                                  # assert_integerish :73
     theta = np.ascontiguousarray(theta, dtype=np.float64)
-    ctx = ctx or _lib.default_context(N)
-    if ctx.max_particles < N:
-        ctx = _lib.default_context(N)
+    dim = models.dim_of(model)
+    ctx = ctx or _lib.default_context(N, dim=dim)
+    if ctx.max_particles < N or ctx.max_dim < dim:
+        ctx = _lib.default_context(N, dim=dim)
     max_trans, max_res = noise_shape(algorithm, T, ot)
-    state_est = np.zeros(T + 1)
+    state_est = np.zeros((T + 1, dim)) if dim > 1 else np.zeros(T + 1)
     ess = np.zeros(T + 1)
     llh = np.zeros(max(T, 1))
     ll = np.zeros(1)
@@ -62,17 +63,18 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
     nres = np.zeros(1, dtype=np.int32)
     resampled = np.zeros(max(T, 1), dtype=np.int32)
     anc = np.zeros((max(max_res, 1), N), dtype=np.int32) if return_ancestors else None
-    ph = np.zeros((T + 1, N)) if return_particles else None
+    ph = np.zeros((T + 1, N * dim)) if return_particles else None
     wh = np.zeros((T + 1, N)) if return_particles else None
     ms = np.zeros(1)
     scan_stats = np.zeros(3, dtype=np.int64)
     zi = zt = ur = None
     if draws is not None:
-        zi = np.ascontiguousarray(draws["z_init"], dtype=np.float64)
-        zt = np.ascontiguousarray(draws["z_trans"], dtype=np.float64)
         ur = np.ascontiguousarray(draws["u_res"], dtype=np.float64)
-        assert zi.size >= N and zt.size >= max_trans * N
         assert ur.size >= max_res * (1 if resample_fn == "systematic" else N)
+        if model != "sir":       # SIR draws a data-dependent number of variates: always the device generator
+            zi = np.ascontiguousarray(draws["z_init"], dtype=np.float64)
+            zt = np.ascontiguousarray(draws["z_trans"], dtype=np.float64)
+            assert zi.size >= N and zt.size >= max_trans * N
     cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
                         _lib.RESAMPLE_FN[resample_fn], N, T, -1.0 if threshold is None else float(threshold),
                         _ptr(theta), int(theta.size), _ptr(y), _ptr(ot), int(seed), int(stream),

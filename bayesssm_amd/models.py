@@ -37,6 +37,32 @@ class Model:
         self.log_likelihood_fn = ModelFn(name, "log_likelihood", ("sigma_y",))
         self.aux_log_likelihood_fn = ModelFn(name, "aux_log_likelihood", ("phi", "sigma_y"))
         self.dim = 1
+        self.param_order = self.PARAM_ORDER
+        self.constants = ()
+
+
+class SirModel(Model):
+    """Stochastic SIR of vignettes/articles/stochastic-sir-model.Rmd:143-176,285-310: state (s, i), one Gillespie
+    day per transition (rates lambda/n_total * s * i and gamma * i), y ~ Poisson(i).  `n_total` and the initial
+    state are the vignette's globals (:143-148); the sampled parameters are (lambda, gamma)."""
+    PARAM_ORDER = ("lambda", "gamma")
+
+    def __init__(self, n_total=500, init_infected=70):
+        self.name = "sir"
+        self.init_fn = ModelFn("sir", "init", ())
+        self.transition_fn = ModelFn("sir", "transition", ("lambda", "gamma"))
+        self.log_likelihood_fn = ModelFn("sir", "log_likelihood", ())
+        # look-ahead used by auxiliary_filter (the reference defines none for this model): Poisson at the one-day mean of i
+        self.aux_log_likelihood_fn = ModelFn("sir", "aux_log_likelihood", ("lambda", "gamma"))
+        self.dim = 2
+        self.param_order = self.PARAM_ORDER
+        self.constants = (float(n_total), float(n_total - init_infected), float(init_infected))
+        for fn in (self.init_fn, self.transition_fn, self.log_likelihood_fn, self.aux_log_likelihood_fn):
+            fn.owner = self
+
+
+def sir(n_total=500, init_infected=70):
+    return SirModel(n_total, init_infected)
 
 
 def linear_gaussian():
@@ -70,7 +96,11 @@ def resolve(init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn=Non
 
 
 def theta_from_kwargs(fns, kwargs):
-    """Collect (phi, sigma_x, sigma_y) from the named arguments the functions read."""
+    """Collect the model's parameter vector from the named arguments the functions read
+    (lg / ar1sin: phi, sigma_x, sigma_y;  sir: lambda, gamma, then the constants n_total, s0, i0)."""
+    kwargs = dict(kwargs)
+    if "lambda_" in kwargs:                       # `lambda` is a Python keyword
+        kwargs["lambda"] = kwargs.pop("lambda_")
     needed = []
     for fn in fns:
         for p in fn.params:
@@ -79,4 +109,11 @@ def theta_from_kwargs(fns, kwargs):
     for p in needed:
         if p not in kwargs:
             raise TypeError('argument "%s" is missing, with no default' % p)   # R's message for a missing closure arg
+    owner = getattr(fns[0], "owner", None)
+    if owner is not None:
+        return [float(kwargs.get(p, 1.0)) for p in owner.param_order] + list(owner.constants)
     return [float(kwargs.get(p, 1.0)) for p in Model.PARAM_ORDER]
+
+
+def dim_of(model_name):
+    return 2 if model_name == "sir" else 1

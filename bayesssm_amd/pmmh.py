@@ -37,6 +37,11 @@ def prior_uniform(lo=0.0, hi=1.0):
     return Prior("uniform", lo, hi)
 
 
+def prior_halfnormal(sigma=1.0):
+    """function(x) extraDistr::dhnorm(x, sigma, log = TRUE)   (stochastic-sir-model.Rmd:267-274)"""
+    return Prior("halfnormal", sigma, 0.0)
+
+
 def prior_flat():
     """function(x) 0"""
     return Prior("flat")
@@ -91,7 +96,7 @@ def gather_chains(local, num_chains, m, p, dist=None):
 
 def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov, transform, priors, num_particles,
                      seed, chain_index, obs_times=None, resample_algorithm="SISAR", resample_fn="stratified",
-                     return_latent_state_est=False, ctx=None):
+                     return_latent_state_est=False, ctx=None, model_constants=None):
     """One chain of R/pmmh.R:403-415,422-500 on this process's GPU (bssm_pmmh_chain)."""
     y = np.ascontiguousarray(y, dtype=np.float64)
     T = y.size
@@ -107,14 +112,18 @@ def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov
     pk = np.ascontiguousarray([_lib.PRIOR[p.kind] for p in priors], dtype=np.int32)
     pa = np.ascontiguousarray([p.a for p in priors], dtype=np.float64)
     pb = np.ascontiguousarray([p.b for p in priors], dtype=np.float64)
+    dim = models.dim_of(model)
+    if ctx.max_dim < dim:
+        ctx = _lib.default_context(num_particles, dim=dim)
+    consts = np.ascontiguousarray(list(init_theta) + list(model_constants or ()), dtype=np.float64)
     pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
-                       _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, None, n_params, ptr(y), ptr(ot),
-                       int(seed), 0, None, None, None, 0, 0)
+                       _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, ptr(consts), int(consts.size),
+                       ptr(y), ptr(ot), int(seed), 0, None, None, None, 0, 0)
     cfg = _lib.PmmhConfig(pf, int(m), int(n_params), ptr(init_theta), ptr(cov), ptr(tr), ptr(pk), ptr(pa), ptr(pb),
                           int(seed), int(chain_index), 1 if return_latent_state_est else 0)
     theta_chain = np.zeros((m, n_params))
     ll_chain = np.zeros(m)
-    se_chain = np.zeros((m, T + 1)) if return_latent_state_est else None
+    se_chain = np.zeros((m, T + 1, dim) if dim > 1 else (m, T + 1)) if return_latent_state_est else None
     acc = np.zeros(1, dtype=np.int32)
     ms = np.zeros(1)
     res = _lib.PmmhResult(ptr(theta_chain), ptr(ll_chain), ptr(se_chain), ptr(acc), ptr(ms))
@@ -181,8 +190,10 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
             param_transform = dict(param_transform, **{k: "identity" for k in bad})
     else:
         raise ValueError("param_transform must be a list.")
-    if prior_names != list(models.Model.PARAM_ORDER):
-        raise ValueError("log_priors must be given in the order %s for the built-in models" % (models.Model.PARAM_ORDER,))
+    owner = getattr(init_fn, "owner", None)
+    order = list(owner.param_order) if owner is not None else list(models.Model.PARAM_ORDER)
+    if prior_names != order:
+        raise ValueError("log_priors must be given in the order %s for this built-in model" % (tuple(order),))
     transform = [param_transform[k] for k in prior_names]
     priors = [log_priors[k] for k in prior_names]
     if num_particles is None or proposal_cov is None:
@@ -216,7 +227,8 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
         r = runner(pf_wrapper=pf_wrapper, y=y, m=m, model=model, n_params=n_params, init_theta=init_theta,
                    proposal_cov=proposal_cov, transform=transform, priors=priors, num_particles=num_particles,
                    seed=int(seeds[c]), chain_index=c, obs_times=obs_times, resample_algorithm=pf_ra,
-                   resample_fn=pf_rf, return_latent_state_est=return_latent_state_est)
+                   resample_fn=pf_rf, return_latent_state_est=return_latent_state_est,
+                   model_constants=(owner.constants if owner is not None else None))
         local[c] = r["theta_chain"]
         extras[c] = r
     chains = gather_chains(local, num_chains, m, n_params, dist)          # (num_chains, m, p)

@@ -48,6 +48,8 @@ extern "C" {
 /* ---- enums (values match the oracle's) ---------------------------------- */
 #define BSSM_MODEL_LG 0       /* x' = phi x + N(0,sx);            y ~ N(x, sy)   tests/testthat/test-pmmh_tuning.R:163-173 */
 #define BSSM_MODEL_AR1SIN 1   /* x' = phi x + sin x + N(0,sx);    y ~ N(x, sy)   README.md:137-146 */
+#define BSSM_MODEL_SIR 2      /* stochastic SIR, state (s, i), Gillespie day, y ~ Poisson(i);
+                                 theta = (lambda, gamma, n_total, s0, i0)          vignettes/articles/stochastic-sir-model.Rmd:143-176,285-310 */
 
 #define BSSM_BPF 0            /* bootstrap_filter  */
 #define BSSM_APF 1            /* auxiliary_filter  */
@@ -68,6 +70,7 @@ extern "C" {
 #define BSSM_PRIOR_EXP 1      /* dexp(x, rate=a, log=TRUE) */
 #define BSSM_PRIOR_UNIFORM 2  /* dunif(x, a, b, log=TRUE)  */
 #define BSSM_PRIOR_FLAT 3     /* 0                          */
+#define BSSM_PRIOR_HALFNORMAL 4 /* extraDistr::dhnorm(x, sigma = a, log=TRUE)  (stochastic-sir-model.Rmd:267-274) */
 
 typedef struct bssm_ctx bssm_ctx;
 
@@ -138,7 +141,7 @@ typedef struct {
 } bssm_pf_config;
 
 typedef struct {
-    double* state_est;        /* (T+1) x d                                     */
+    double* state_est;        /* (T+1) x d, row-major (d = 1; 2 for the SIR model) */
     double* ess;              /* T+1                                           */
     double* loglike_history;  /* T, cumulative (R/particle_filter_core.R:209)  */
     double* loglike;          /* 1                                             */
@@ -190,7 +193,7 @@ typedef struct {
 typedef struct {
     double* theta_chain;       /* m x n_params, row-major                         */
     double* loglike_chain;     /* m                                               */
-    double* state_est_chain;   /* m x (T+1), or NULL                              */
+    double* state_est_chain;   /* m x (T+1) x d, or NULL                          */
     int* accepted;             /* 1: number of accepted proposals                 */
     double* device_ms;         /* 1 or NULL: summed filter device time            */
 } bssm_pmmh_result;

@@ -41,7 +41,7 @@
 /* R's M_LN_SQRT_2PI (Rmath.h): log(sqrt(2*pi)) */
 #define ORC_LN_SQRT_2PI 0.918938533204672741780329736406
 
-enum { ORC_MODEL_LG = 0, ORC_MODEL_AR1SIN = 1 };
+enum { ORC_MODEL_LG = 0, ORC_MODEL_AR1SIN = 1, ORC_MODEL_SIR = 2 };
 enum { ORC_BPF = 0, ORC_APF = 1 };
 enum { ORC_SIS = 0, ORC_SISR = 1, ORC_SISAR = 2 };
 enum { ORC_STRATIFIED = 0, ORC_SYSTEMATIC = 1, ORC_MULTINOMIAL = 2 };
@@ -224,6 +224,71 @@ static void orc_aux_loglik(int model, const double *theta, int N, const double *
 }
 
 /* ------------------------------------------------------------------------- */
+/* Stochastic SIR model (vignettes/articles/stochastic-sir-model.Rmd)          */
+/* ------------------------------------------------------------------------- */
+/* The closures draw a DATA-DEPENDENT number of variates (rexp / runif per Gillespie event,
+ * :152-176), so they cannot be injected as fixed-shape arrays.  Draws are therefore keyed by
+ * (particle, event, transition call) through the Philox4x32-10 counter-based generator
+ * (Salmon et al., SC'11 -- a published third-party algorithm, restated here independently of
+ * the product's csrc/rng.h; checked against Random123's known answers in
+ * tests/test_oracle_golden.py), with the same key layout the device uses. */
+typedef struct { uint32_t x, y, z, w; } orc_u32x4;
+
+orc_u32x4 orc_philox4x32_10(orc_u32x4 c, uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        orc_u32x4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0; n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1; n.w = (uint32_t)p0;
+        c = n; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+static double orc_u01(uint32_t lo, uint32_t hi)
+{
+    uint64_t b = ((uint64_t)hi << 32) | lo;
+    return ((double)(b >> 11) + 0.5) * 0x1.0p-53;
+}
+void orc_philox_kat(const uint32_t *ctr, const uint32_t *key, uint32_t *out)
+{
+    orc_u32x4 c = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    orc_u32x4 r = orc_philox4x32_10(c, key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+typedef struct { uint32_t k0, k1, stream; } orc_key;
+
+/* epidemic_step, stochastic-sir-model.Rmd:152-176; transition_fn_epidemic :294-304 */
+static void orc_sir_transition(double *s, double *i, double lambda, double gamma, double n_total,
+                               orc_key key, uint32_t call, uint32_t particle)
+{
+    if (*i == 0) return;                                             /* :297-299 */
+    double t = 0; uint32_t ev = 0;
+    while (t < 1.0 && *i > 0) {                                      /* t_end = 1 */
+        double rate_infection = (lambda / n_total) * (*s) * (*i);
+        double rate_removal = gamma * (*i);
+        double rate_total = rate_infection + rate_removal;
+        if (rate_total <= 0) break;
+        orc_u32x4 c = {particle, call, 2u | (ev << 8), key.stream};  /* purpose 2 = transition draw */
+        orc_u32x4 r = orc_philox4x32_10(c, key.k0, key.k1);
+        double dt = -log(orc_u01(r.x, r.y)) / rate_total;            /* rexp(1, rate_total) */
+        if (t + dt > 1.0) break;
+        t = t + dt;
+        if (orc_u01(r.z, r.w) < rate_infection / rate_total) { *s -= 1; *i += 1; }   /* infection */
+        else { *i -= 1; }                                                              /* removal   */
+        ev++;
+    }
+}
+/* dpois(y, lambda, log = TRUE); log_likelihood_fn_epidemic :306-309 */
+static double orc_dpois_log(double y, double lambda)
+{
+    if (lambda <= 0) return (y == 0 && lambda == 0) ? 0.0 : -INFINITY;
+    if (y == 0) return -lambda;
+    return y * log(lambda) - lambda - lgamma(y + 1.0);
+}
+
+/* ------------------------------------------------------------------------- */
 /* .particle_filter_core: R/particle_filter_core.R:19-267 (d = 1 models)      */
 /* ------------------------------------------------------------------------- */
 
@@ -238,8 +303,9 @@ typedef struct {
     const double *z_init;   /* [N] standard normals for init_fn */
     const double *z_trans;  /* [n_trans_calls][N], consumed in call order */
     const double *u_res;    /* systematic: [n_res_calls]; stratified/multinomial: [n_res_calls][N] */
+    unsigned long long seed, stream;  /* SIR only: key of the Gillespie draws */
     /* outputs */
-    double *state_est;      /* [T+1] */
+    double *state_est;      /* [T+1][d] */
     double *ess;            /* [T+1] */
     double *loglike_history;/* [T]   */
     double *loglike;        /* [1]   */
@@ -279,8 +345,12 @@ int orc_pf_run(orc_pf_args *a)
     }
     const size_t ures_stride = (a->resample_fn == ORC_SYSTEMATIC) ? 1 : (size_t)N;
 
-    double *x = (double *)malloc(sizeof(double) * N);
-    double *xold = (double *)malloc(sizeof(double) * N);
+    const int sir = (a->model == ORC_MODEL_SIR);
+    const int D = sir ? 2 : 1;
+    orc_key key = {(uint32_t)a->seed, (uint32_t)(a->seed >> 32),
+                   (uint32_t)a->stream ^ (uint32_t)((a->stream >> 32) * 0x9E3779B9u)};
+    double *x = (double *)malloc(sizeof(double) * N * D);      /* [D][N] */
+    double *xold = (double *)malloc(sizeof(double) * N * D);
     double *lw = (double *)malloc(sizeof(double) * N);
     double *auxlw = (double *)malloc(sizeof(double) * N);
     double *w = (double *)malloc(sizeof(double) * N);
@@ -289,17 +359,20 @@ int orc_pf_run(orc_pf_args *a)
     int rc = ORC_OK, ktrans = 0, kres = 0;
     *a->early_return_step = 0;
 
-    /* init_fn: rnorm(N, 0, 1) :76 */
-    for (int i = 0; i < N; i++) x[i] = orc_rnorm(0.0, 1.0, a->z_init[i]);
+    /* init_fn: rnorm(N, 0, 1) :76   (SIR: every particle at (s0, i0), stochastic-sir-model.Rmd:286-293) */
+    if (sir) { for (int i = 0; i < N; i++) { x[i] = a->theta[3]; x[N + i] = a->theta[4]; } }
+    else for (int i = 0; i < N; i++) x[i] = orc_rnorm(0.0, 1.0, a->z_init[i]);
 
     /* t = 0 :106-116.  weights = rep(1/N, N); ess[1] = 1/sum(w^2); state_est[1] = sum(x*w) */
     for (int i = 0; i < N; i++) w[i] = 1.0 / dN;
     for (int i = 0; i < N; i++) tmp[i] = w[i] * w[i];
     a->ess[0] = 1.0 / orc_rsum(N, tmp);
-    for (int i = 0; i < N; i++) tmp[i] = x[i] * w[i];
-    a->state_est[0] = orc_rsum(N, tmp);
+    for (int d = 0; d < D; d++) {
+        for (int i = 0; i < N; i++) tmp[i] = x[(size_t)d * N + i] * w[i];
+        a->state_est[d] = orc_rsum(N, tmp);                    /* colSums(particles * weights) :111 */
+    }
     if (a->weights_hist) memcpy(a->weights_hist, w, sizeof(double) * N);
-    if (a->particles_hist) memcpy(a->particles_hist, x, sizeof(double) * N);
+    if (a->particles_hist) memcpy(a->particles_hist, x, sizeof(double) * N * D);
 
     double loglike = 0.0;
     int prev_t = 0;
@@ -307,14 +380,20 @@ int orc_pf_run(orc_pf_args *a)
         const int ot = a->obs_times ? a->obs_times[i - 1] : i;
         const int gap = ot - prev_t;                          /* :124 */
         for (int step = 1; step <= gap; step++) {             /* :125-136 */
-            orc_transition(a->model, a->theta, N, x, a->z_trans + (size_t)ktrans * N);
+            if (sir) { for (int k = 0; k < N; k++) orc_sir_transition(&x[k], &x[N + k], a->theta[0], a->theta[1], a->theta[2], key, (uint32_t)ktrans, (uint32_t)k); }
+            else orc_transition(a->model, a->theta, N, x, a->z_trans + (size_t)ktrans * N);
             ktrans++;
         }
         prev_t = ot;
         const double yi = a->y[i - 1];
 
         if (a->algorithm == ORC_APF) {                        /* :140-175 */
-            orc_aux_loglik(a->model, a->theta, N, x, yi, auxlw);
+            if (sir) {   /* this build's look-ahead for SIR: Poisson at the one-day mean of i (the reference defines none) */
+                for (int k = 0; k < N; k++) {
+                    double m = x[N + k] + (a->theta[0] / a->theta[2]) * x[k] * x[N + k] - a->theta[1] * x[N + k];
+                    auxlw[k] = orc_dpois_log(yi, m > 0 ? m : 0.0);
+                }
+            } else orc_aux_loglik(a->model, a->theta, N, x, yi, auxlw);
             double max_aux = auxlw[0];
             for (int k = 1; k < N; k++) if (auxlw[k] > max_aux) max_aux = auxlw[k];
             for (int k = 0; k < N; k++) tmp[k] = exp(auxlw[k] - max_aux);   /* :153 */
@@ -325,14 +404,17 @@ int orc_pf_run(orc_pf_args *a)
             if (rc != ORC_OK) goto done;
             if (a->ancestors) memcpy(a->ancestors + (size_t)kres * N, idx, sizeof(int) * N);
             kres++;
-            memcpy(xold, x, sizeof(double) * N);
-            for (int k = 0; k < N; k++) x[k] = xold[idx[k] - 1];            /* :157 */
-            orc_transition(a->model, a->theta, N, x, a->z_trans + (size_t)ktrans * N); /* :159 */
+            memcpy(xold, x, sizeof(double) * N * D);
+            for (int d = 0; d < D; d++) for (int k = 0; k < N; k++) x[(size_t)d * N + k] = xold[(size_t)d * N + idx[k] - 1];   /* :157 */
+            if (sir) { for (int k = 0; k < N; k++) orc_sir_transition(&x[k], &x[N + k], a->theta[0], a->theta[1], a->theta[2], key, (uint32_t)ktrans, (uint32_t)k); }
+            else orc_transition(a->model, a->theta, N, x, a->z_trans + (size_t)ktrans * N); /* :159 */
             ktrans++;
-            orc_loglik(a->model, a->theta, N, x, yi, lw);                    /* :169-174 */
+            if (sir) { for (int k = 0; k < N; k++) lw[k] = orc_dpois_log(yi, x[N + k]); }
+            else orc_loglik(a->model, a->theta, N, x, yi, lw);               /* :169-174 */
             for (int k = 0; k < N; k++) lw[k] = lw[k] - auxlw[idx[k] - 1];   /* :175 */
         } else {
-            orc_loglik(a->model, a->theta, N, x, yi, lw);                    /* :177-182 */
+            if (sir) { for (int k = 0; k < N; k++) lw[k] = orc_dpois_log(yi, x[N + k]); }
+            else orc_loglik(a->model, a->theta, N, x, yi, lw);               /* :177-182 */
         }
 
         int all_small = 1;                                    /* :189 all(log_weights < -1e8) */
@@ -365,15 +447,17 @@ int orc_pf_run(orc_pf_args *a)
             if (rc != ORC_OK) goto done;
             if (a->ancestors) memcpy(a->ancestors + (size_t)kres * N, idx, sizeof(int) * N);
             kres++;
-            memcpy(xold, x, sizeof(double) * N);
-            for (int k = 0; k < N; k++) x[k] = xold[idx[k] - 1];            /* R/resampling.R:40,60 */
+            memcpy(xold, x, sizeof(double) * N * D);
+            for (int d = 0; d < D; d++) for (int k = 0; k < N; k++) x[(size_t)d * N + k] = xold[(size_t)d * N + idx[k] - 1];   /* R/resampling.R:40,60 */
             for (int k = 0; k < N; k++) w[k] = 1.0 / dN;
             a->ess[i] = dN;                                   /* :223 */
         }
-        for (int k = 0; k < N; k++) tmp[k] = x[k] * w[k];
-        a->state_est[i] = orc_rsum(N, tmp);                   /* :238 */
+        for (int d = 0; d < D; d++) {
+            for (int k = 0; k < N; k++) tmp[k] = x[(size_t)d * N + k] * w[k];
+            a->state_est[(size_t)i * D + d] = orc_rsum(N, tmp);              /* :238-240 */
+        }
         if (a->weights_hist) memcpy(a->weights_hist + (size_t)i * N, w, sizeof(double) * N);
-        if (a->particles_hist) memcpy(a->particles_hist + (size_t)i * N, x, sizeof(double) * N);
+        if (a->particles_hist) memcpy(a->particles_hist + (size_t)i * N * D, x, sizeof(double) * N * D);
     }
 done:
     *a->loglike = loglike;

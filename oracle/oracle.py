@@ -20,7 +20,7 @@ ERROR_STRINGS = {
     ERR_ZERO_SUM: "Sum of weights must be greater than 0",     # src/resampling.cpp:8,22,49
     ERR_LENGTH: "Number of particles must match the length of weights",  # R/resampling.R:17
 }
-MODEL = {"lg": 0, "ar1sin": 1}
+MODEL = {"lg": 0, "ar1sin": 1, "sir": 2}
 ALGORITHM = {"BPF": 0, "APF": 1}
 RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
 RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2}
@@ -45,6 +45,7 @@ class _PfArgs(C.Structure):
         ("threshold", C.c_double),
         ("theta", C.c_void_p), ("y", C.c_void_p), ("obs_times", C.c_void_p),
         ("z_init", C.c_void_p), ("z_trans", C.c_void_p), ("u_res", C.c_void_p),
+        ("seed", C.c_ulonglong), ("stream", C.c_ulonglong),
         ("state_est", C.c_void_p), ("ess", C.c_void_p), ("loglike_history", C.c_void_p),
         ("loglike", C.c_void_p), ("ancestors", C.c_void_p), ("weights_hist", C.c_void_p),
         ("particles_hist", C.c_void_p),
@@ -130,7 +131,7 @@ def noise_shape(algorithm, T, obs_times=None):
 
 def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
            resample_algorithm="SISAR", resample_fn="stratified", threshold=None,
-           obs_times=None, return_ancestors=False, return_particles=False):
+           obs_times=None, return_ancestors=False, return_particles=False, seed=0, stream=0):
     """Restatement of .particle_filter_core (R/particle_filter_core.R:19-267)
     with injected random draws.  Returns a dict shaped like the reference's
     result list (state_est, ess, loglike, loglike_history, algorithm[,
@@ -139,25 +140,29 @@ def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
     T = len(y)
     theta = _d(theta)
     ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
-    z_init, z_trans, u_res = _d(z_init), _d(z_trans), _d(u_res)
+    D = 2 if model == "sir" else 1
+    z_init = _d(z_init) if z_init is not None else np.zeros(N)
+    z_trans = _d(z_trans) if z_trans is not None else np.zeros(1)
+    u_res = _d(u_res)
     max_trans, max_res = noise_shape(algorithm, T, obs_times)
-    assert z_init.size >= N
-    assert z_trans.size >= max_trans * N, (z_trans.size, max_trans, N)
+    if model != "sir":
+        assert z_init.size >= N
+        assert z_trans.size >= max_trans * N, (z_trans.size, max_trans, N)
     need_u = max_res * (1 if resample_fn == "systematic" else N)
     assert u_res.size >= need_u, (u_res.size, need_u)
-    state_est = np.zeros(T + 1)
+    state_est = np.zeros((T + 1, D)) if D > 1 else np.zeros(T + 1)
     ess = np.zeros(T + 1)
     llh = np.zeros(T)
     ll = np.zeros(1)
     anc = np.zeros((max_res, N), dtype=np.int32) if return_ancestors else None
     wh = np.full((T + 1, N), np.nan) if return_particles else None
-    ph = np.full((T + 1, N), np.nan) if return_particles else None
+    ph = np.full((T + 1, N * D), np.nan) if return_particles else None
     nt, nr, ers = (np.zeros(1, dtype=np.int32) for _ in range(3))
     resampled = np.zeros(max(T, 1), dtype=np.int32)
     a = _PfArgs(MODEL[model], ALGORITHM[algorithm], RESAMPLE_ALGORITHM[resample_algorithm],
                 RESAMPLE_FN[resample_fn], N, T,
                 -1.0 if threshold is None else float(threshold),
-                _p(theta), _p(y), _p(ot), _p(z_init), _p(z_trans), _p(u_res),
+                _p(theta), _p(y), _p(ot), _p(z_init), _p(z_trans), _p(u_res), int(seed), int(stream),
                 _p(state_est), _p(ess), _p(llh), _p(ll), _p(anc), _p(wh), _p(ph),
                 _p(nt), _p(nr), _p(ers), _p(resampled))
     st = lib().orc_pf_run(C.byref(a))
@@ -175,6 +180,14 @@ def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
         res["particles_history"] = ph
         res["weights_history"] = wh
     return res
+
+
+def philox4x32_10(ctr, key):
+    c = np.ascontiguousarray(ctr, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox_kat(_p(c), _p(k), _p(out))
+    return out
 
 
 def transform_params(theta, tr):

@@ -1,0 +1,102 @@
+"""GPU parity for BASELINE C4's model: stochastic SIR (state dimension 2, data-dependent Gillespie loop,
+Poisson observations; vignettes/articles/stochastic-sir-model.Rmd:143-176,285-310) through bootstrap_filter
+and auxiliary_filter.  The Gillespie draws cannot be injected (their number depends on the data), so both sides
+use the counter-based generator with the same (seed, stream) -- the oracle's independent C restatement of
+Philox4x32-10 -- and the resampling uniforms are injected as usual."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THETA = (0.5, 0.2)            # true lambda, gamma of the vignette (:147-148)
+
+
+@pytest.fixture(scope="module")
+def B():
+    import bayesssm_amd as b
+    return b
+
+
+@pytest.fixture(scope="module")
+def ctx(B):
+    return B.Context(0, 1 << 18, 2)
+
+
+def _simulate(rng, T, n_total=500, i0=70, lam=0.5, gam=0.2):
+    s, i, ys = float(n_total - i0), float(i0), []
+    for _ in range(T):
+        t = 0.0
+        while t < 1.0 and i > 0:
+            ri, rr = lam / n_total * s * i, gam * i
+            dt = rng.exponential(1.0 / (ri + rr))
+            if t + dt > 1.0:
+                break
+            t += dt
+            if rng.random() < ri / (ri + rr):
+                s, i = s - 1, i + 1
+            else:
+                i -= 1
+        ys.append(float(rng.poisson(i)))
+    return np.array(ys)
+
+
+def _compare(res, ref):
+    assert abs(res["loglike"] - ref["loglike"]) <= 1e-6 * max(1.0, abs(ref["loglike"]))
+    np.testing.assert_allclose(res["loglike_history"], ref["loglike_history"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(res["ess"], ref["ess"], rtol=1e-6)
+    np.testing.assert_allclose(res["state_est"], ref["state_est"], rtol=1e-6, atol=1e-8)
+    assert (res["_extras"]["resampled"] == ref["resampled"]).all()
+
+
+@pytest.mark.parametrize("rf", ["stratified", "systematic"])
+@pytest.mark.parametrize("ra", ["SISAR", "SISR"])
+def test_sir_bpf(B, ctx, oracle, rf, ra):
+    rng = np.random.default_rng(5)
+    T, N = 12, 3000
+    ys = _simulate(rng, T)
+    m = B.models.sir()
+    ur = rng.random(T) if rf == "systematic" else rng.random((T, N))
+    res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm=ra,
+                             resample_fn=rf, return_particles=True, draws={"u_res": ur}, seed=11, stream=3, ctx=ctx,
+                             lambda_=THETA[0], gamma=THETA[1])
+    ref = oracle.pf_run("sir", [THETA[0], THETA[1], 500, 430, 70], ys, N, None, None, ur, resample_algorithm=ra,
+                        resample_fn=rf, return_particles=True, seed=11, stream=3)
+    _compare(res, ref)
+    assert res["state_est"].shape == (T + 1, 2) and res["particles_history"].shape == (T + 1, 2 * N)
+    # integer-valued states travel exactly: the whole history must agree except where a weight ulp flipped an ancestor
+    same = (res["particles_history"] == ref["particles_history"]).mean()
+    assert same > 0.999
+    assert res["state_est"][0].tolist() == [430.0, 70.0]
+
+
+def test_sir_apf(B, ctx, oracle):
+    rng = np.random.default_rng(6)
+    T, N = 10, 2500
+    ys = _simulate(rng, T)
+    m = B.models.sir()
+    ur = rng.random((2 * T, N))
+    res = B.auxiliary_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, m.aux_log_likelihood_fn,
+                             draws={"u_res": ur}, seed=2, stream=9, ctx=ctx, return_particles=False,
+                             lambda_=THETA[0], gamma=THETA[1])
+    ref = oracle.pf_run("sir", [THETA[0], THETA[1], 500, 430, 70], ys, N, None, None, ur, algorithm="APF", seed=2, stream=9)
+    _compare(res, ref)
+
+
+def test_sir_c4_size_and_pmmh(B, ctx):
+    """BASELINE C4 size (N = 2^18, APF) on a short series: structure + a short PMMH chain over (lambda, gamma)
+    with the vignette's half-normal priors (:267-274)."""
+    from bayesssm_amd.pmmh import run_chain_device, prior_halfnormal
+    rng = np.random.default_rng(1405)
+    ys = _simulate(rng, 20)
+    m = B.models.sir()
+    r = B.auxiliary_filter(ys, 1 << 18, m.init_fn, m.transition_fn, m.log_likelihood_fn, m.aux_log_likelihood_fn,
+                           seed=1, ctx=ctx, return_particles=False, lambda_=0.5, gamma=0.2)
+    assert r["state_est"].shape == (21, 2) and np.isfinite(r["loglike"])
+    assert np.all(np.abs(r["state_est"][1:, 0] + r["state_est"][1:, 1]) <= 500.0 + 1e-9)
+    ch = run_chain_device(pf_wrapper=B.bootstrap_filter, y=ys, m=120, model="sir", n_params=2, init_theta=[0.4, 0.3],
+                          proposal_cov=np.diag([4e-4, 4e-4]), transform=["log", "log"],
+                          priors=[prior_halfnormal(1), prior_halfnormal(2)], num_particles=4096, seed=3, chain_index=0,
+                          ctx=ctx, model_constants=m.constants)
+    th = ch["theta_chain"][40:]
+    assert 0.05 < ch["accepted"] / 120 < 0.98
+    assert 0.2 < th[:, 0].mean() < 0.9 and 0.05 < th[:, 1].mean() < 0.5

@@ -162,3 +162,21 @@ def test_mcmc_ess(oracle):
     mat = rng.standard_normal((1000, 3))
     e = oracle.mcmc_ess(mat)
     assert 2000 < e < 4500
+
+
+def test_oracle_philox_kat(oracle):
+    """The oracle's own Philox4x32-10 (used only by its SIR closures) against Random123's known answers."""
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        assert tuple(int(v) for v in oracle.philox4x32_10(ctr, key)) == want
+
+
+def test_oracle_sir_runs(oracle):
+    rng = np.random.default_rng(0)
+    ys = [75, 80, 88, 95, 100, 104, 108, 110, 108, 105]
+    r = oracle.pf_run("sir", [0.5, 0.2, 500, 430, 70], ys, 400, None, None, rng.random((10, 400)), seed=7, stream=1)
+    assert r["state_est"].shape == (11, 2) and r["state_est"][0].tolist() == [430.0, 70.0]
+    assert np.isfinite(r["loglike"]) and np.all(r["state_est"].sum(axis=1) <= 500 + 1e-9)
