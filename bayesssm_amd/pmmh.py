@@ -21,6 +21,24 @@ class Prior:
     def __init__(self, kind, a=0.0, b=1.0):
         self.kind, self.a, self.b = kind, float(a), float(b)
 
+    def __call__(self, x):
+        """log-density, as the R closure in `log_priors` would return it (host side; the device chain
+        loop evaluates the same formulas in bssm_pmmh_chain)."""
+        x = float(x)
+        if self.kind == "normal":
+            z = (x - self.a) / self.b
+            return -(0.918938533204672741780329736406 + 0.5 * z * z + np.log(self.b))
+        if self.kind == "exponential":
+            return -np.inf if x < 0 else np.log(self.a) - self.a * x
+        if self.kind == "uniform":
+            return -np.log(self.b - self.a) if self.a <= x <= self.b else -np.inf
+        if self.kind == "halfnormal":
+            if x < 0:
+                return -np.inf
+            z = x / self.a
+            return np.log(2.0) - (0.918938533204672741780329736406 + 0.5 * z * z + np.log(self.a))
+        return 0.0
+
 
 def prior_normal(mean=0.0, sd=1.0):
     """function(x) dnorm(x, mean, sd, log = TRUE)"""
@@ -61,6 +79,79 @@ def default_tune_control(pilot_proposal_sd=0.5, pilot_n=100, pilot_m=2000, pilot
             "pilot_target_var": pilot_target_var, "pilot_burn_in": pilot_burn_in, "pilot_reps": pilot_reps,
             "pilot_resample_algorithm": _match_arg(pilot_resample_algorithm, _RESAMPLE_ALGORITHMS, "pilot_resample_algorithm"),
             "pilot_resample_fn": _match_arg(pilot_resample_fn, _RESAMPLE_FNS, "pilot_resample_fn")}
+
+
+def _transform(theta, tr):
+    """.transform_params (R/utils.R:102-112)"""
+    return np.array([np.log(t) if k == "log" else np.log(t / (1 - t)) if k == "logit" else t for t, k in zip(theta, tr)])
+
+
+def _back_transform(z, tr):
+    """.back_transform_params (R/utils.R:122-132)"""
+    return np.array([np.exp(v) if k == "log" else 1 / (1 + np.exp(-v)) if k == "logit" else v for v, k in zip(z, tr)])
+
+
+def _log_jacobian(theta, tr):
+    """.compute_log_jacobian (R/utils.R:142-152)"""
+    return float(sum(np.log(t) if k == "log" else np.log(1 / (t * (1 - t))) if k == "logit" else 0.0
+                     for t, k in zip(theta, tr)))
+
+
+def pilot_run(pf, pilot_n, pilot_reps):
+    """.pilot_run (R/pmmh_tuning.R:29-64): repeat the filter `pilot_reps` times at `pilot_n` particles and size
+    the main chain's particle count from the variance of the log-likelihood estimates."""
+    lls = np.array([pf(pilot_n, rep) for rep in range(pilot_reps)])
+    variance_estimate = float(np.var(lls, ddof=1))
+    target_n = int(np.ceil(pilot_n * variance_estimate)) if np.isfinite(variance_estimate) else 1000
+    target_n = min(max(target_n, 50), 1000)                                   # :55-57
+    return {"variance_estimate": variance_estimate, "target_n": target_n, "pilot_loglikes": lls}
+
+
+def run_pilot_chain(pf, pilot_m, pilot_n, pilot_reps, priors, proposal_sd, transform, pilot_init_params, rng,
+                    verbose=False, message=print):
+    """.run_pilot_chain (R/pmmh_tuning.R:111-317): random-walk MH with independent normal proposals on the
+    transformed scale, burn-in = half, posterior mean / covariance, then .pilot_run at the posterior mean.
+    `pf(theta, n, tag)` runs one filter and returns its log-likelihood; host draws come from `rng`."""
+    p = len(priors)
+    lp0 = [pr(v) for pr, v in zip(priors, pilot_init_params)]
+    if not np.all(np.isfinite(lp0)):
+        raise ValueError("Initial parameter values are invalid: some lie outside the prior support. "
+                         "Please provide valid starting values via pilot_init_params.")       # :133-138
+    cur = np.array(pilot_init_params, dtype=np.float64)
+    chain = np.empty((pilot_m, p))
+    llc = np.empty(pilot_m)
+    chain[0] = cur
+    cur_ll = pf(cur, pilot_n, 0)
+    llc[0] = cur_ll
+    proposal_sd = np.resize(np.asarray(proposal_sd, dtype=np.float64), p)                      # rep(..., length.out)
+    for i in range(1, pilot_m):                                                                # for (m in 2:pilot_m) :188
+        while True:                                                                            # :190-206
+            prop = _back_transform(_transform(cur, transform) + rng.standard_normal(p) * proposal_sd, transform)
+            lp_prop = np.array([pr(v) for pr, v in zip(priors, prop)])
+            if np.all(np.isfinite(lp_prop)):
+                break
+        lp_cur = np.array([pr(v) for pr, v in zip(priors, cur)])
+        prop_ll = pf(prop, pilot_n, i)
+        num = lp_prop.sum() + prop_ll + _log_jacobian(prop, transform)
+        den = lp_cur.sum() + cur_ll + _log_jacobian(cur, transform)
+        lar = num - den
+        if np.isnan(lar):
+            lar = -np.inf                                                                      # :248
+        if np.log(rng.random()) < lar:
+            cur, cur_ll = prop, prop_ll
+        chain[i] = cur
+        llc[i] = cur_ll
+    burn = pilot_m // 2                                                                        # :260
+    post = chain[burn:]
+    mean = post.mean(axis=0)
+    cov = np.cov(post, rowvar=False).reshape(p, p) if p > 1 else np.array([[post[:, 0].var(ddof=1)]])
+    if verbose:
+        message("Pilot chain posterior mean:")
+        message(str(mean))
+    pr_ = pilot_run(lambda n, rep: pf(mean, n, 10_000_000 + rep), pilot_n, pilot_reps)
+    message("Using %d particles for PMMH:" % pr_["target_n"])                                  # :308
+    return {"pilot_theta_mean": mean, "pilot_theta_cov": cov, "target_n": pr_["target_n"],
+            "pilot_theta_chain": chain, "pilot_loglike_chain": llc, "variance_estimate": pr_["variance_estimate"]}
 
 
 def chain_assignment(num_chains, world_size):
@@ -139,9 +230,10 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     """pmmh (R/pmmh.R:243-630) on the device path.
 
     Deviations from the reference, both stated in DESIGN.md:
-      * `num_particles` / `proposal_cov` override the pilot's target_n (capped at 1000 in the reference,
-        R/pmmh_tuning.R:55-57) and pilot covariance; the pilot run itself is not part of this build yet,
-        so both are REQUIRED.  The chain starts at pilot_init_params[[chain]].
+      * `num_particles` / `proposal_cov` (extra arguments) override the pilot's target_n (capped at 1000 in the
+        reference, R/pmmh_tuning.R:55-57) and pilot covariance; when BOTH are given the pilot chain is skipped and
+        the chain starts at pilot_init_params[[chain]].  Otherwise the pilot (.run_pilot_chain,
+        R/pmmh_tuning.R:111-317) runs first: its MH loop on the host, every filter run on the GPU.
       * as in the reference, `resample_algorithm` / `resample_fn` are validated but NOT forwarded to the
         main chain's filter calls (R/pmmh.R:403-415; tests/testthat/test-pmmh.R:404-466): the wrapper
         defaults (SISAR, stratified) apply, unless `pf_resample_algorithm` / `pf_resample_fn` are given.
@@ -196,10 +288,7 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
         raise ValueError("log_priors must be given in the order %s for this built-in model" % (tuple(order),))
     transform = [param_transform[k] for k in prior_names]
     priors = [log_priors[k] for k in prior_names]
-    if num_particles is None or proposal_cov is None:
-        raise NotImplementedError(
-            "pilot tuning (.run_pilot_chain, R/pmmh_tuning.R) is not part of this build: pass num_particles= and "
-            "proposal_cov= (SURVEY.md 8f-1)")
+    use_pilot = num_particles is None or proposal_cov is None
     if seed is None:
         seed = int(np.random.default_rng().integers(1, 2 ** 31 - 1))
     # per-chain seeds drawn up-front, so results do not depend on how chains are placed (R/pmmh.R:511)
@@ -219,18 +308,45 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     local, extras = {}, {}
     pf_ra = kwargs.pop("pf_resample_algorithm", "SISAR")
     pf_rf = kwargs.pop("pf_resample_fn", "stratified")
+    tune_control = dict(tune_control)
     for c in mine:
         init_theta = [float(pilot_init_params[c][k]) for k in prior_names]
         if verbose:
             print("Running chain %d..." % (c + 1))
+        chain_n, chain_cov = num_particles, proposal_cov
+        if use_pilot:
+            # Step 1 of chain_result (R/pmmh.R:353-376): pilot chain -> start, proposal covariance, particle count
+            if verbose:
+                print("Running pilot chain for tuning...")
+            algorithm = "APF" if pf_wrapper is auxiliary_filter else "BPF"
+            owner_c = getattr(init_fn, "owner", None)
+            consts = list(owner_c.constants) if owner_c is not None else []
+            from .filters import particle_filter_core
+
+            def pf_ll(theta, n, tag, _c=c):
+                r = particle_filter_core(y, int(n), model, list(theta) + consts, algorithm, obs_times,
+                                         tune_control["pilot_resample_algorithm"], tune_control["pilot_resample_fn"],
+                                         None, False, seed=int(seeds[_c]), stream=(1 << 40) + int(tag))
+                return r["loglike"]
+
+            pilot = run_pilot_chain(pf_ll, tune_control["pilot_m"], tune_control["pilot_n"], tune_control["pilot_reps"],
+                                    priors, tune_control["pilot_proposal_sd"], transform, init_theta,
+                                    np.random.default_rng([int(seeds[c]), 77]), verbose,
+                                    message=(print if verbose else (lambda *_: None)))
+            init_theta = [float(v) for v in pilot["pilot_theta_mean"]]
+            chain_cov = pilot["pilot_theta_cov"] if proposal_cov is None else proposal_cov
+            chain_n = pilot["target_n"] if num_particles is None else num_particles
+            extras_pilot = pilot
         runner = _chain_runner or run_chain_device
         r = runner(pf_wrapper=pf_wrapper, y=y, m=m, model=model, n_params=n_params, init_theta=init_theta,
-                   proposal_cov=proposal_cov, transform=transform, priors=priors, num_particles=num_particles,
+                   proposal_cov=chain_cov, transform=transform, priors=priors, num_particles=chain_n,
                    seed=int(seeds[c]), chain_index=c, obs_times=obs_times, resample_algorithm=pf_ra,
                    resample_fn=pf_rf, return_latent_state_est=return_latent_state_est,
                    model_constants=(owner.constants if owner is not None else None))
         local[c] = r["theta_chain"]
         extras[c] = r
+        if use_pilot:
+            extras[c]["pilot"] = extras_pilot
     chains = gather_chains(local, num_chains, m, n_params, dist)          # (num_chains, m, p)
     post = chains[:, burn_in:, :]                                         # drop burn-in (R/pmmh.R:540-545)
     diag_ess, diag_rhat = {}, {}

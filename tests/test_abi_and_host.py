@@ -117,3 +117,25 @@ def test_rng_header_on_host(oracle):
     ps = np.concatenate([np.linspace(1e-15, 1 - 1e-15, 2001), 10.0 ** -np.arange(2, 16), [0.5, 0.075, 0.925]])
     got = np.array([lib.h_qnorm(float(p)) for p in ps])
     np.testing.assert_allclose(got, stats.norm.ppf(ps), rtol=2e-14, atol=1e-15)
+
+
+def test_pilot_chain_logic():
+    """.run_pilot_chain / .pilot_run (R/pmmh_tuning.R:29-64,111-317) with a synthetic filter: target_n bounds
+    (tests/testthat/test-pmmh_tuning.R:48,102) and posterior mean near the optimum (:573-575)."""
+    from bayesssm_amd.pmmh import run_pilot_chain, pilot_run, prior_normal, prior_exponential
+    rng = np.random.default_rng(0)
+
+    def pf(theta, n, tag):
+        return float(-25 * np.sum((np.asarray(theta) - np.array([0.5, 1.0])) ** 2) + rng.standard_normal() * 0.3)
+
+    r = run_pilot_chain(pf, 400, 100, 50, [prior_normal(0, 1), prior_exponential(1)], 0.5, ["identity", "log"],
+                        [0.2, 0.7], np.random.default_rng(1), message=lambda *_: None)
+    assert 50 <= r["target_n"] <= 1000
+    assert abs(r["pilot_theta_mean"][0] - 0.5) < 0.2 and abs(r["pilot_theta_mean"][1] - 1.0) < 0.3
+    assert r["pilot_theta_cov"].shape == (2, 2) and r["pilot_theta_chain"].shape == (400, 2)
+    lo = pilot_run(lambda n, rep: 0.0 + 1e-3 * rep, 100, 10)
+    hi = pilot_run(lambda n, rep: 10.0 * rep, 100, 10)
+    assert lo["target_n"] == 50 and hi["target_n"] == 1000                     # clamp :55-57
+    with pytest.raises(ValueError, match="Initial parameter values are invalid"):
+        run_pilot_chain(pf, 10, 100, 5, [prior_normal(0, 1), prior_exponential(1)], 0.5, ["identity", "log"],
+                        [0.2, -1.0], np.random.default_rng(1), message=lambda *_: None)

@@ -225,3 +225,26 @@ def test_pmmh_chain_device(B, ctx, oracle):
     assert not (a["theta_chain"] == b2["theta_chain"]).all()
     assert 0.05 < a["accepted"] / 300 < 0.95
     assert abs(a["theta_chain"][100:, 0].mean() - 0.8) < 0.25
+
+
+def test_pmmh_with_pilot(B, ctx, oracle):
+    """pmmh() end to end with the pilot (R/pmmh.R:353-376 + R/pmmh_tuning.R): README-sized run
+    (README.md:150-195: m = 500, burn_in = 50, 2 chains, pilot_m = 200)."""
+    import warnings
+    rng = np.random.default_rng(1405)
+    ys = _simulate(rng, 20, 0.8, 1.0, 0.5, sin=True)
+    m = B.models.ar1_sin()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = B.pmmh(B.bootstrap_filter, ys, 300, m.init_fn, m.transition_fn, m.log_likelihood_fn,
+                     log_priors={"phi": B.prior_normal(0, 1), "sigma_x": B.prior_exponential(1), "sigma_y": B.prior_exponential(1)},
+                     pilot_init_params=[{"phi": 0.8, "sigma_x": 1.0, "sigma_y": 0.5}, {"phi": 1.0, "sigma_x": 0.5, "sigma_y": 1.0}],
+                     burn_in=50, num_chains=2, seed=1405,
+                     param_transform={"phi": "identity", "sigma_x": "log", "sigma_y": "log"},
+                     tune_control=B.default_tune_control(pilot_m=200, pilot_burn_in=10, pilot_reps=20))
+    th = res["theta_chain"]
+    assert len(th["phi"]) == 2 * 250 and set(th["chain"].tolist()) == {1, 2}
+    for c in (0, 1):
+        assert 50 <= res["_extras"]["local_chains"][c]["pilot"]["target_n"] <= 1000
+    assert 0.2 < th["phi"].mean() < 1.3 and th["sigma_x"].min() > 0 and th["sigma_y"].min() > 0
+    assert set(res["diagnostics"]["ess"]) == {"phi", "sigma_x", "sigma_y"}
