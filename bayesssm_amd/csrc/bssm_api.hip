@@ -163,6 +163,10 @@ extern "C" void* bssm_ctx_stream(bssm_ctx* c) { return c ? (void*)c->stream : nu
 // Development aid (tools/ only, not part of the ABI in include/): scan kernels return after stage N.
 static int g_debug_stop = 0;
 extern "C" void bssm_debug_set_stop(int stage) { g_debug_stop = stage; }
+// Test aid: override the validity window of the scan records (ulps).  A tiny window makes the per-lane
+// verification fail almost everywhere, which drives the literal fallbacks of the real kernels.
+static int g_debug_lim = 0;
+extern "C" void bssm_debug_set_window(int lim) { g_debug_lim = lim; }
 __global__ void k_set_debug(DevState* st, int v) { st->debug_stop = v; }
 extern "C" int bssm_debug_get_stamps(bssm_ctx* c, long long* out /* [4][16] */)
 {
@@ -245,7 +249,7 @@ struct ResampleLaunch {
 static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
 {
     const int B = (int)((r.nw + EB - 1) / EB);
-    const int lim = rec_window(r.nw);
+    const int lim = g_debug_lim > 0 ? g_debug_lim : rec_window(r.nw);
     const size_t shm = (size_t)B * sizeof(BlockRec);
     FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
     f.ain_out = c->ain_w; f.plan = r.plan; f.N = r.nw; f.obs_i = r.obs_i; f.resample_algorithm = r.resample_algorithm;
@@ -286,9 +290,7 @@ static int resample_common_device(bssm_ctx* c, int kind, int n, const double* d_
     LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
     if (g_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, g_debug_stop);
     LAUNCH(c, "k_bsum", k_bsum, B, NT, 0, d_w, (long long)nw, c->bsum, c->st);
-    LAUNCH(c, "k_plan<resample>", k_plan<PLAN_RESAMPLE_ONLY>, 1, NT, 0, (const double*)nullptr, (const double*)nullptr, 0,
-           c->bsum, (const double*)nullptr, B, c->ain_w, c->st, (long long)nw, 0, 0, 0.0,
-           (double*)nullptr, (double*)nullptr, (int*)nullptr);
+    LAUNCH(c, "k_plan", k_plan, 1, NT, 0, c->bsum, B, c->ain_w, c->st);
     ResampleLaunch r;
     r.d_w = d_w; r.nw = nw; r.n = n; r.kind = kind; r.d_u = d_u; r.u_stride = (kind == BSSM_SYSTEMATIC) ? 1 : n;
     r.key = make_key(0, 0); r.d_anc = d_idx; r.anc_stride = 0; r.d_cum = d_cum;

@@ -3,14 +3,17 @@
 // Hot path of the reference, per observation (R/particle_filter_core.R:123-246):
 //   transition_fn -> weight_fn -> max/exp/sum normalise -> loglik, ESS ->
 //   resample_fn (src/resampling.cpp) -> gather -> state estimate.
-// Kernel map (one launch each, all on the context's stream):
-//   k_step        propagate (+ log-weight, + per-block log-sum-exp partial)   :127,:177-183,:204-206
-//   k_normalize   w = exp(lw - max)/sum, per-block sum w and sum w^2          :205-207,:211
-//   k_plan        loglik / ESS / resample decision; approximate block prefixes :208-218
-//   k_local<W|P>  per-block "records" of the exact sequential sum (seqsum.h)  src/resampling.cpp:20,25
-//   k_resolve<>   exact incoming state of every block; exact total            src/resampling.cpp:20
-//   k_apply<>     exact cum_sum -> output counts -> ancestors -> gather        src/resampling.cpp:28-37, R/resampling.R:40
-//   k_multinomial inverse-CDF search on the exact cum_sum                      src/resampling.cpp:11 (distributional)
+// Kernel map (one launch each, all on the context's stream; 6 launches per observation with resampling):
+//   k_step / k_step_sir   transition_fn + weight_fn + per-block (max, sum exp, sum exp^2) partials   :127,:177-183
+//   k_local<W, from_lw>   w = exp(lw - max)/sum (:205-207); loglik / ESS / resample decision from the partials
+//                         (:208-218); block records of the exact sequential sum(w)               src/resampling.cpp:20
+//   k_resolve<W>          exact total = sum(w) (one workgroup)                                   src/resampling.cpp:20
+//   k_local<P>            block records of cumsum(w / total)                                     src/resampling.cpp:24-25
+//   k_resolve<P>          exact incoming state of every block (one workgroup)
+//   k_apply<kind>         exact cum_sum -> output counts -> ancestors -> particles[indices, ]    src/resampling.cpp:28-37, R/resampling.R:40
+//   k_multinomial         inverse-CDF search on the exact cum_sum                                src/resampling.cpp:11 (distributional)
+//   k_carry               no resample at this observation: carry particles, sum(x * w)           :238
+//   k_bsum, k_plan        stand-alone resampler front end (validation, approximate block prefixes)
 // Particles are SoA: x[dim][N] doubles; weights/log-weights [N]; ancestors int32.
 //
 // All arithmetic that the reference defines is done in fp64 with contraction
@@ -190,13 +193,6 @@ __device__ __forceinline__ double block_excl_scan(double x, double* sh4)
     double pre = 0.0;
     for (int i = 0; i < wave; i++) pre += sh4[i];
     return pre + exc;
-}
-
-// (max, sum exp(. - max)) pairs: combine b into a
-__device__ __forceinline__ void lse_combine(double& m, double& s, double mb, double sb)
-{
-    if (mb > m) { s = s * exp(m - mb) + sb; m = mb; }
-    else if (mb > -INFINITY) { s = s + sb * exp(mb - m); }
 }
 
 // Reduce the per-block (max, sumexp) partials to the global pair; every
@@ -430,39 +426,6 @@ __global__ __launch_bounds__(NTS) void k_step_sir(const double* xin, double* xou
     }
 }
 
-// ---------------------------------------------------------------------------
-// k_normalize: weights = exp(lw - max) / sum  (:205-207), per-block plain sums
-// of w (approximate prefix for the exact scan) and of w^2 (ESS, :211)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_normalize(const double* __restrict__ lw, double* __restrict__ w, long long N,
-                                                  const double* __restrict__ pm, const double* __restrict__ ps, int nb,
-                                                  double* __restrict__ bsum, double* __restrict__ bsq,
-                                                  int check_degenerate, DevState* st)
-{
-    if (st->dead) return;
-    __shared__ double sh4[4];
-    double M, S;
-    reduce_lse_partials(pm, ps, nb, sh4, M, S);
-    if (check_degenerate && M < -1e8) return;   // degenerate: k_plan marks the run dead (:189)
-    const long long base = (long long)blockIdx.x * EB;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < EL / 2; r++) {
-        const long long j = base + 2 * (threadIdx.x + NT * r);
-        if (j < N) {
-            const double w0 = exp(lw[j] - M) / S;
-            w[j] = w0; s1 += w0; s2 += w0 * w0;
-            if (j + 1 < N) { const double w1 = exp(lw[j + 1] - M) / S; w[j + 1] = w1; s1 += w1; s2 += w1 * w1; }
-        }
-    }
-    s1 = block_sum(s1, sh4);
-    s2 = block_sum(s2, sh4);
-    if (threadIdx.x == 0) {
-        bsum[blockIdx.x] = s1; bsq[blockIdx.x] = s2;
-        if (!isfinite(s1)) atomicOr(&st->flags, FLAG_NONFINITE);   // NaN/Inf log-weights: the scan kernels stand down
-    }
-}
-
 // stand-alone resampler front end: validation (src/resampling.cpp:6,18,45) + block sums
 __global__ __launch_bounds__(NT) void k_bsum(const double* __restrict__ w, long long nw, double* __restrict__ bsum, DevState* st)
 {
@@ -486,49 +449,13 @@ __global__ __launch_bounds__(NT) void k_bsum(const double* __restrict__ w, long 
 }
 
 // ---------------------------------------------------------------------------
-// k_plan (one workgroup): scalars of the observation + approximate exclusive
-// block prefixes ain[b] for the exact scan.
+// k_plan (one workgroup, stand-alone resampler only): approximate exclusive block prefixes ain[b] from the
+// block sums.  (In the filter these come from the log-sum-exp partials inside k_local<W, from_lw>.)
 // ---------------------------------------------------------------------------
-template <int PLAN>
-__global__ __launch_bounds__(NT) void k_plan(const double* __restrict__ pm, const double* __restrict__ ps, int nb_lse,
-                                             const double* __restrict__ bsum, const double* __restrict__ bsq, int B,
-                                             double* __restrict__ ain, DevState* st, long long N,
-                                             int obs_i /* 1-based */, int resample_algorithm, double threshold,
-                                             double* __restrict__ ess_out, double* __restrict__ llh_out, int* __restrict__ resampled_out)
+__global__ __launch_bounds__(NT) void k_plan(const double* __restrict__ bsum, int B, double* __restrict__ ain, DevState* st)
 {
     __shared__ double sh4[4];
-    if (PLAN != PLAN_RESAMPLE_ONLY) {
-        if (st->dead) return;
-        if (PLAN == PLAN_PF) {
-            double M, S;
-            reduce_lse_partials(pm, ps, nb_lse, sh4, M, S);
-            if (M < -1e8) {                     // all(log_weights < -1e8)  (:189-202)
-                if (threadIdx.x == 0) {
-                    st->loglike = -INFINITY; llh_out[obs_i - 1] = -INFINITY; st->dead = obs_i; st->do_resample = 0;
-                }
-                return;
-            }
-            double q = 0.0;
-            for (int i = threadIdx.x; i < B; i += NT) q += bsq[i];
-            q = block_sum(q, sh4);
-            if (threadIdx.x == 0) {
-                const double ll = st->loglike + (M + log(S) - log((double)N));   // :208
-                st->loglike = ll; llh_out[obs_i - 1] = ll;                        // :209
-                const double ess = 1.0 / q;                                       // :211
-                const int doit = (resample_algorithm == 0) ? 0 : (resample_algorithm == 1) ? 1 : (ess < threshold);  // :214-218
-                st->do_resample = doit;
-                ess_out[obs_i] = doit ? (double)N : ess;                          // :212,:223
-                if (resampled_out) resampled_out[obs_i - 1] = doit;
-                st->ess = ess; st->lse_max = M; st->lse_sum = S;
-                if (doit) { st->cur_call = st->res_calls; st->res_calls += 1; }
-            }
-        } else {
-            if (threadIdx.x == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
-        }
-    } else {
-        if (threadIdx.x == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
-    }
-    // exclusive scan of the block sums (B <= MAXB = NT * 8)
+    if (threadIdx.x == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
     double loc[MAXB / NT];
     double tsum = 0.0;
 #pragma unroll
@@ -952,14 +879,11 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
         for (int k = 0; k < EL; k++) v[k] = (MODE == MODE_P) ? vraw[k] / total : vraw[k];   // prob = weights / total (src/resampling.cpp:24,51)
         a_in = a_in_pre;
     }
-    if (dbg == 1) { if (v[0] + v[7] == -1.0) tin[t] = 1; return; }
     BSSM_STAMP(st, dbg, 2, 1, stamper && v[0] >= 0.0);
     BlockScan bs;
     block_scan<MODE>(sm, v, a_in, lim, bs);
     __syncthreads();
     BSSM_STAMP(st, dbg, 2, 2, stamper);
-    if (dbg == 2) { if (bs.exc.d0 == -12345) tin[t] = 1; return; }
-    if (dbg == 3 && a_in == 0.0) return;
     const uint64_t hb0 = d2b(a_in) & ~3ull;
     if (a_in == 0.0) {
         // exact incoming state (+0): resolve now and publish the exact outgoing state
@@ -1145,9 +1069,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     if (t == 0) sm.fail = 0;
     __syncthreads();
     if (s_dead || s_flags || !s_do) return;
-    const int dbg = dbg0;
     BSSM_STAMP(st, dbg0, MODE, 2, t == 0);
-    if (dbg == 11) return;
     const double total = (MODE == MODE_P) ? b2d(s_total) : 1.0;
     const int CB = (B + NTR - 1) / NTR;                // blocks per thread (1 or 2)
     const int c0 = t * CB, c1 = (c0 + CB < B) ? c0 + CB : B;
@@ -1170,12 +1092,10 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     }
     if (c0 >= B) { isb = false; comp.d0 = comp.d1 = 0; }    // padding lanes: identity
     BSSM_STAMP(st, dbg0, MODE, 3, t == 0);
-    if (dbg == 12) { if (comp.d0 == -12345) cin[0] = 1; return; }
     int seg, nb; Pure lastseg;
     const Pure exc = seg_excl_scan<NTR / 64>(sm, comp, isb, seg, nb, lastseg);
     if (isb && seg < MAXBND) { sm.bnd_excl[seg] = exc; sm.bnd_lane[seg] = t; }
     __syncthreads();
-    if (dbg == 13) { if (exc.d0 == -12345) cin[0] = 1; return; }
     BSSM_STAMP(st, dbg0, MODE, 4, t == 0);
     long long lit = 0;
     // ---- boundary walk.  One wave; lane j owns the j-th boundary block with its record in registers; the
@@ -1253,7 +1173,6 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     BSSM_STAMP(st, dbg0, MODE, 5, t == 0);
     __syncthreads();
     BSSM_STAMP(st, dbg0, MODE, 6, t == 0);
-    if (dbg == 14) return;
     uint64_t ent = 0;
     if (!sm.fail && c0 < B && !isb) {
         ent = pure_step(exc, sm.seg_start[seg]);
@@ -1342,17 +1261,14 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     BSSM_STAMP(st, dbg, 3, 0, stamper);
 #pragma unroll
     for (int k = 0; k < EL; k++) v[k] = v[k] / total;                  // prob = weights / total (src/resampling.cpp:24,51)
-    if (dbg == 1) { if (v[0] + v[7] == -1.0) Tl[t] = 1; return; }
     BSSM_STAMP(st, dbg, 3, 1, stamper && v[0] >= 0.0);
     BlockScan bs;
     block_scan<MODE_P>(sm, v, a_in_p, a.lim, bs);
     __syncthreads();
     BSSM_STAMP(st, dbg, 3, 2, stamper);
-    if (dbg == 2) { if (bs.exc.d0 == -12345) Tl[t] = 1; return; }
     uint64_t ent;
     const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
     if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
-    if (dbg == 3) { if (ent == 12345) Tl[t] = 1; return; }
     BSSM_STAMP(st, dbg, 3, 3, stamper);
     // the reference chain itself, from the exact incoming state
     UniformSrc us;
@@ -1373,7 +1289,6 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
         Tl[t * EL + k] = T;
     }
     if (KIND == 2) return;                                            // multinomial: k_multinomial searches cum_out
-    if (dbg == 4) return;
     BSSM_STAMP(st, dbg, 3, 4, stamper);
     if (t == 0) {
         int tb = 0;

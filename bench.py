@@ -85,17 +85,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev
+    backend = os.environ.get("BENCH_BACKEND", "nccl")       # "gloo" only to rehearse the control flow on one GPU
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     import bayesssm_amd as b
 
     N, T = args.particles, args.T
     theta = (0.8, 1.0, 1.0)
     ys = simulate_lg(T)
     m = b.models.linear_gaussian()
-    ctx = b.Context(local_rank if world > 1 else 0, N, 1)
+    ctx = b.Context(dev_index if world > 1 else 0, N, 1)
 
     def run(stream):
         return b.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn,
@@ -120,7 +126,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     psteps = float(N) * T * args.steps * world

@@ -143,3 +143,29 @@ def test_proportions(B, ctx):
             U = rng.random() if fn is B.resample_systematic_cpp else rng.random(5)
             counts += np.bincount(fn(5, w, U=U, ctx=ctx) - 1, minlength=5)
         np.testing.assert_allclose(counts / (reps * 5), w, atol=0.05)
+
+
+@pytest.mark.parametrize("lim", [1, 5, 200])
+def test_fallback_paths_stay_exact(B, ctx, oracle, lim):
+    """Shrink the records' validity window (test-only knob of the library) so that the per-lane verification
+    fails and the kernels' literal fallbacks run: results must stay bit-exact."""
+    from bayesssm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(lim)
+    try:
+        lib.bssm_debug_set_window(lim)
+        total_fallbacks = 0
+        for n, kind in ((5000, "uniformish"), (70000, "skewed"), (300000, "uniformish"), (40000, "range")):
+            w = _weights(rng, n, kind)
+            U = rng.random()
+            got, cum, stats = B.resample_systematic_cpp(n, w, U=U, ctx=ctx, return_cum=True, return_stats=True)
+            want, wcum = oracle.resample_systematic(n, w, U, return_cum=True)
+            assert cum.tobytes() == wcum.tobytes()
+            assert (got == want).all()
+            total_fallbacks += int(stats[1]) + int(stats[2])
+            Us = rng.random(n)
+            assert (B.resample_stratified_cpp(n, w, U=Us, ctx=ctx) == oracle.resample_stratified(n, w, Us)).all()
+        if lim <= 5:
+            assert total_fallbacks > 0, "the tiny window did not exercise any fallback"
+    finally:
+        lib.bssm_debug_set_window(0)

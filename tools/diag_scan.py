@@ -1,5 +1,4 @@
-"""Dev tool: per-stage timing of the scan kernels via the debug early-exit knob (results are
-meaningless for stage != 0; only the kernel durations are)."""
+"""Dev tool (obsolete stage knob removed from the kernels): per-kernel event timing of the stand-alone resampler."""
 import sys; sys.path.insert(0, '.')
 import numpy as np, bayesssm_amd as b
 from bayesssm_amd import _lib
@@ -8,7 +7,7 @@ ctx = b.Context(0, 1 << 22, 1)
 rng = np.random.default_rng(1)
 n = 1 << 20
 w = np.exp(-0.5 * rng.standard_normal(n) ** 2); w /= w.sum()
-for stage in (11, 12, 13, 14, 0):
+for stage in (0,):
     lib.bssm_debug_set_stop(stage)
     ctx.set_profile(True)
     for rep in range(4):
