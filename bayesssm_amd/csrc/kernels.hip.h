@@ -1325,17 +1325,34 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
             p = T;
         }
         __syncthreads();
-        for (int r = t; r < nout; r += NT) {
-            const int lo = own[r];
-            const long long src = b0 + lo;
-            const int i = Tb + r;
-            if (anc) anc[i] = (int)(src + 1);                        // 1-based (src/resampling.cpp:36,62)
-            if (a.xdst) {
-                const double x0 = a.xsrc[src];
-                a.xdst[i] = x0; acc0 += x0 * invN;
-                if (a.dim > 1) { const double x1 = a.xsrc[a.xstride + src]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
+        // outputs in order, 8 per lane per round: all owner look-ups, then all gathers (independent loads in
+        // flight together), then the stores -- one memory round trip per round instead of one per output
+        for (int r0 = 0; r0 < nout; r0 += NT * EL) {
+            int lo[EL];
+            double x0[EL], x1[EL], ax[EL];
+#pragma unroll
+            for (int k = 0; k < EL; k++) { const int r = r0 + t + NT * k; lo[k] = (r < nout) ? (int)own[r] : -1; }
+#pragma unroll
+            for (int k = 0; k < EL; k++) {
+                x0[k] = 0.0; x1[k] = 0.0; ax[k] = 0.0;
+                if (lo[k] >= 0) {
+                    const long long src = b0 + lo[k];
+                    if (a.xdst) { x0[k] = a.xsrc[src]; if (a.dim > 1) x1[k] = a.xsrc[a.xstride + src]; }
+                    if (a.auxdst) ax[k] = a.auxsrc[src];
+                }
             }
-            if (a.auxdst) a.auxdst[i] = a.auxsrc[src];
+#pragma unroll
+            for (int k = 0; k < EL; k++) {
+                if (lo[k] >= 0) {
+                    const int i = Tb + r0 + t + NT * k;
+                    if (anc) anc[i] = (int)(b0 + lo[k] + 1);         // 1-based (src/resampling.cpp:36,62)
+                    if (a.xdst) {
+                        a.xdst[i] = x0[k]; acc0 += x0[k] * invN;
+                        if (a.dim > 1) { a.xdst[a.xstride + i] = x1[k]; acc1 += x1[k] * invN; }
+                    }
+                    if (a.auxdst) a.auxdst[i] = ax[k];
+                }
+            }
         }
     } else {
         for (int i = Tb + t; i < Te; i += NT) {
