@@ -165,8 +165,14 @@ def main():
             dom = next(iter(kern))
             nbytes = KERNEL_BYTES.get(dom, 0.0) * N
             ach = nbytes / (kern[dom]["avg_us"] * 1e-6) / 1e9 if nbytes else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+            if N == 1 << 20 and os.path.exists(tpath):
+                # fabric-side bytes per launch of this kernel, from committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
+                # see the file's "source"); not collected live
+                traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("bytes_per_launch_corrected")
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": kern[dom]["avg_us"]}
         else:
             out["roofline"] = {"bound": "hbm", "kernel": "whole sweep", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS,
