@@ -309,11 +309,13 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     pf_ra = kwargs.pop("pf_resample_algorithm", "SISAR")
     pf_rf = kwargs.pop("pf_resample_fn", "stratified")
     tune_control = dict(tune_control)
-    for c in mine:
+
+    def one_chain(c, ctx_c):
         init_theta = [float(pilot_init_params[c][k]) for k in prior_names]
         if verbose:
             print("Running chain %d..." % (c + 1))
         chain_n, chain_cov = num_particles, proposal_cov
+        pilot = None
         if use_pilot:
             # Step 1 of chain_result (R/pmmh.R:353-376): pilot chain -> start, proposal covariance, particle count
             if verbose:
@@ -326,7 +328,7 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
             def pf_ll(theta, n, tag, _c=c):
                 r = particle_filter_core(y, int(n), model, list(theta) + consts, algorithm, obs_times,
                                          tune_control["pilot_resample_algorithm"], tune_control["pilot_resample_fn"],
-                                         None, False, seed=int(seeds[_c]), stream=(1 << 40) + int(tag))
+                                         None, False, seed=int(seeds[_c]), stream=(1 << 40) + int(tag), ctx=ctx_c)
                 return r["loglike"]
 
             pilot = run_pilot_chain(pf_ll, tune_control["pilot_m"], tune_control["pilot_n"], tune_control["pilot_reps"],
@@ -336,17 +338,53 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
             init_theta = [float(v) for v in pilot["pilot_theta_mean"]]
             chain_cov = pilot["pilot_theta_cov"] if proposal_cov is None else proposal_cov
             chain_n = pilot["target_n"] if num_particles is None else num_particles
-            extras_pilot = pilot
         runner = _chain_runner or run_chain_device
-        r = runner(pf_wrapper=pf_wrapper, y=y, m=m, model=model, n_params=n_params, init_theta=init_theta,
-                   proposal_cov=chain_cov, transform=transform, priors=priors, num_particles=chain_n,
-                   seed=int(seeds[c]), chain_index=c, obs_times=obs_times, resample_algorithm=pf_ra,
-                   resample_fn=pf_rf, return_latent_state_est=return_latent_state_est,
-                   model_constants=(owner.constants if owner is not None else None))
-        local[c] = r["theta_chain"]
-        extras[c] = r
-        if use_pilot:
-            extras[c]["pilot"] = extras_pilot
+        kw = dict(pf_wrapper=pf_wrapper, y=y, m=m, model=model, n_params=n_params, init_theta=init_theta,
+                  proposal_cov=chain_cov, transform=transform, priors=priors, num_particles=chain_n,
+                  seed=int(seeds[c]), chain_index=c, obs_times=obs_times, resample_algorithm=pf_ra,
+                  resample_fn=pf_rf, return_latent_state_est=return_latent_state_est,
+                  model_constants=(owner.constants if owner is not None else None))
+        if ctx_c is not None:
+            kw["ctx"] = ctx_c
+        r = runner(**kw)
+        if pilot is not None:
+            r["pilot"] = pilot
+        return r
+
+    # Chains of one rank are independent (R/pmmh.R:511-531): with several chains on this GPU, run up to
+    # `chains_per_gpu` of them at once, each on its own context (= HIP stream); a single filter leaves most of the
+    # chip idle between its dependent launches, two or three concurrent chains fill it.
+    conc = int(kwargs.pop("chains_per_gpu", 2 if _chain_runner is None else 1))
+    conc = max(1, min(conc, len(mine)))
+    if conc > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        dim_c = models.dim_of(model)
+        cap = int(num_particles) if num_particles is not None else 1024
+        import queue
+        ctxs = [_lib.Context(_lib.default_context(1).device, max(cap, 1024), dim_c) for _ in range(conc)]
+        free = queue.Queue()
+        for cx in ctxs:
+            free.put(cx)
+
+        def task(c):
+            cx = free.get()                 # a context serves one chain at a time
+            try:
+                return one_chain(c, cx)
+            finally:
+                free.put(cx)
+
+        try:
+            with ThreadPoolExecutor(conc) as ex:
+                futs = {c: ex.submit(task, c) for c in mine}
+                results = {c: futs[c].result() for c in mine}
+        finally:
+            for cx in ctxs:
+                cx.close()
+    else:
+        results = {c: one_chain(c, None) for c in mine}
+    for c in mine:
+        local[c] = results[c]["theta_chain"]
+        extras[c] = results[c]
     chains = gather_chains(local, num_chains, m, n_params, dist)          # (num_chains, m, p)
     post = chains[:, burn_in:, :]                                         # drop burn-in (R/pmmh.R:540-545)
     diag_ess, diag_rhat = {}, {}

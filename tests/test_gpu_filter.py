@@ -248,3 +248,24 @@ def test_pmmh_with_pilot(B, ctx, oracle):
         assert 50 <= res["_extras"]["local_chains"][c]["pilot"]["target_n"] <= 1000
     assert 0.2 < th["phi"].mean() < 1.3 and th["sigma_x"].min() > 0 and th["sigma_y"].min() > 0
     assert set(res["diagnostics"]["ess"]) == {"phi", "sigma_x", "sigma_y"}
+
+
+def test_pmmh_concurrent_chains_match_sequential(B, ctx):
+    """Several chains on one GPU run concurrently on separate contexts; results must equal the one-at-a-time run
+    bit for bit (placement independence, tests/testthat/test-pmmh.R:499-503)."""
+    import warnings
+    rng = np.random.default_rng(3)
+    ys = _simulate(rng, 30)
+    m = B.models.linear_gaussian()
+    kw = dict(pf_wrapper=B.bootstrap_filter, y=ys, m=60, init_fn=m.init_fn, transition_fn=m.transition_fn,
+              log_likelihood_fn=m.log_likelihood_fn,
+              log_priors={"phi": B.prior_normal(0, 1), "sigma_x": B.prior_exponential(1), "sigma_y": B.prior_exponential(1)},
+              pilot_init_params=[{"phi": 0.5 + 0.1 * c, "sigma_x": 1.0, "sigma_y": 1.0} for c in range(4)],
+              burn_in=10, num_chains=4, seed=99, param_transform={"phi": "identity", "sigma_x": "log", "sigma_y": "log"},
+              num_particles=3000, proposal_cov=np.eye(3) * 0.01)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = B.pmmh(chains_per_gpu=1, **kw)
+        b2 = B.pmmh(chains_per_gpu=3, **kw)
+    for k in ("chain", "phi", "sigma_x", "sigma_y"):
+        assert (a["theta_chain"][k] == b2["theta_chain"][k]).all()
