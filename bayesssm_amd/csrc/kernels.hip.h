@@ -506,6 +506,57 @@ __device__ __forceinline__ Pure pure_compose(const Pure& f, const Pure& g)
 }
 __device__ __forceinline__ uint64_t pure_step(const Pure& f, uint64_t in) { return in + (uint64_t)sel_i64(f.d0, f.d1, in); }
 
+// A boundary step "PURE run, then one record" folded into constants, so that the serial walk over the boundaries
+// has a short dependent chain per step:   out = ((s - c) >> sh) + K[c],  c = s & 3.
+// Derivation: e = s + ex.d[c&1];  diff = e - base = (s - c) + R_c with R_c = c + ex.d[c&1] - base and (s - c) a
+// multiple of 4, so the record's hypothesis index is sidx = R_c & 3 and
+//   PURE: out = o[sidx] + (diff - sidx)       = (s - c)      + (o[sidx] + R_c - sidx)
+//   X1  : out = o[sidx] + (diff - sidx) / 2   = (s - c) / 2  + (o[sidx] + (R_c - sidx) / 2).
+// Valid while diff stays in the record's window, i.e. (s - sref) in [wlo, whi].
+struct StepFn {
+    uint64_t K0, K1, K2, K3;
+    uint64_t sref; int64_t wlo, whi;
+    int sh;          // 0 PURE, 1 X1
+    int mode;        // 0 = formula, 1 = constant (ABS), 2 = no fast form (HARD): caller re-runs the terms
+};
+
+__device__ __forceinline__ StepFn stepfn_build(const Pure& ex, const Rec& r)
+{
+    StepFn f; f.K0 = f.K1 = f.K2 = f.K3 = 0; f.sref = 0; f.wlo = 0; f.whi = -1; f.sh = 0; f.mode = 2;
+    if (r.kind == REC_ABS) { f.mode = 1; f.K0 = f.K1 = f.K2 = f.K3 = r.o[0]; return f; }
+    if (r.kind == REC_HARD) return f;
+    f.mode = 0; f.sh = (r.kind == REC_X1) ? 1 : 0;
+    uint64_t K[4];
+    int64_t lo = -(1ll << 62), hi = (1ll << 62);
+    f.sref = r.base - (uint64_t)ex.d0;                       // the incoming state the hypotheses were built around
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint64_t eoff = (uint64_t)((c & 1) ? ex.d1 : ex.d0);
+        const int64_t R = (int64_t)((uint64_t)c + eoff - r.base);
+        const int64_t sidx = R & 3;
+        const uint64_t os = (sidx == 0) ? r.o[0] : (sidx == 1) ? r.o[1] : (sidx == 2) ? r.o[2] : r.o[3];
+        const int64_t rem = R - sidx;                        // multiple of 4
+        K[c] = os + (uint64_t)(f.sh ? (rem >> 1) : rem);
+        // window: r.lo <= (s - c) + R <= r.hi   <=>   s - sref in [r.lo - R + c - (sref offset) ...]
+        const int64_t shift = (int64_t)((uint64_t)c - (uint64_t)R - f.sref);     // s >= r.lo + shift + sref ...
+        const int64_t l = (int64_t)r.lo + shift, h = (int64_t)r.hi + shift;
+        lo = l > lo ? l : lo; hi = h < hi ? h : hi;
+    }
+    f.K0 = K[0]; f.K1 = K[1]; f.K2 = K[2]; f.K3 = K[3];
+    f.wlo = lo + 4; f.whi = hi - 4;
+    return f;
+}
+
+__device__ __forceinline__ uint64_t stepfn_apply(const StepFn& f, uint64_t s, bool& ok)
+{
+    const uint64_t c = s & 3ull;
+    const uint64_t Kc = (c == 0) ? f.K0 : (c == 1) ? f.K1 : (c == 2) ? f.K2 : f.K3;
+    const uint64_t out = ((s - c) >> f.sh) + Kc;
+    const int64_t off = (int64_t)(s - f.sref);
+    ok = (f.mode == 1) || (f.mode == 0 && off >= f.wlo && off <= f.whi);
+    return (f.mode == 1) ? f.K0 : out;
+}
+
 __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off)
 {
     int lo = (int)(uint32_t)(uint64_t)v, hi = (int)(uint32_t)((uint64_t)v >> 32);
@@ -670,18 +721,21 @@ __device__ __forceinline__ bool block_resolve(SegSmem& sm, const BlockScan& bs, 
         Rec rec = rec_identity(0);
         Pure ex; ex.d0 = 0; ex.d1 = 0;
         if (lane < nb) { rec = sm.bnd_rec[lane]; ex = sm.bnd_excl[lane]; }
+        const StepFn fn = stepfn_build(ex, rec);             // "PURE run + this boundary" folded into constants
         uint64_t s = cin, my_ent = 0, my_out = 0;
         for (int j = 0; j < nb; j++) {
-            const uint64_t e = pure_step(ex, s);
-            bool ok = true;
-            uint64_t o = rec_step(rec, e, ok);
-            if (lane == j && !ok) {                      // HARD leaf / window miss: its 8 terms literally, from LDS
-                double c = b2d(e);
+            bool ok;
+            uint64_t o = stepfn_apply(fn, s, ok);
+            if (lane == j) {
+                my_ent = pure_step(ex, s);
+                if (!ok) {                                   // HARD leaf / window miss: its 8 terms literally, from LDS
+                    double c = b2d(my_ent);
 #pragma unroll
-                for (int q = 0; q < EL; q++) c = c + sm.bnd_terms[j][q];
-                o = d2b(c);
+                    for (int q = 0; q < EL; q++) c = c + sm.bnd_terms[j][q];
+                    o = d2b(c);
+                }
+                my_out = o;
             }
-            if (lane == j) { my_ent = e; my_out = o; }
             const int olo = __builtin_amdgcn_readlane((int)(uint32_t)o, j), ohi = __builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), j);
             s = ((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo;
         }
@@ -786,7 +840,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
     if (s_dead || s_flags) return;
     if (!FROM_LW && !s_do) return;
     const bool stamper = (t == 0 && blockIdx.x == (gridDim.x > 100 ? 100u : 0u));
-    BSSM_STAMP(st, dbg, 2, 0, stamper);
+    BSSM_STAMP(st, dbg, 2, FROM_LW ? 4 : 0, stamper);
     double v[EL];
     double a_in;
     if (FROM_LW) {
@@ -804,8 +858,17 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
 #pragma unroll
             for (int k = 0; k < EL; k++) l8[k] = (j0 + k < nw) ? f.lw[j0 + k] : -INFINITY;
         }
+        // all three partial arrays are fetched up front (one memory round trip), then reduced
+        double pmv[MAXB / NT], psv[MAXB / NT], pqv[MAXB / NT];
+#pragma unroll
+        for (int k = 0; k < MAXB / NT; k++) {
+            const int i = t + NT * k;
+            const bool in = i < f.nb;
+            pmv[k] = in ? f.pm[i] : -INFINITY; psv[k] = in ? f.ps[i] : 0.0; pqv[k] = in ? f.pq[i] : 0.0;
+        }
         double m = -INFINITY;
-        for (int i = t; i < f.nb; i += NT) m = fmax(m, f.pm[i]);
+#pragma unroll
+        for (int k = 0; k < MAXB / NT; k++) m = fmax(m, pmv[k]);
         const double M = block_max(m, sm.sh4);
         const bool degenerate = (f.plan == PLAN_PF) && (M < -1e8);       // all(log_weights < -1e8)  (:189-202)
         if (degenerate) {
@@ -815,12 +878,11 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
             return;
         }
         double se = 0.0, sq = 0.0;
-        for (int i = t; i < MAXB; i += NT) {
+#pragma unroll
+        for (int k = 0; k < MAXB / NT; k++) {
+            const int i = t + NT * k;
             double x = 0.0;
-            if (i < f.nb) {
-                const double mb = f.pm[i];
-                if (mb > -INFINITY) { const double ex = exp(mb - M); x = f.ps[i] * ex; sq += f.pq[i] * ex * ex; }
-            }
+            if (pmv[k] > -INFINITY) { const double ex = exp(pmv[k] - M); x = psv[k] * ex; sq += pqv[k] * ex * ex; }
             es[i] = x; se += x;
         }
         const double S = block_sum(se, sm.sh4);              // (block_sum syncs: es[] is complete)
@@ -883,7 +945,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
     BlockScan bs;
     block_scan<MODE>(sm, v, a_in, lim, bs);
     __syncthreads();
-    BSSM_STAMP(st, dbg, 2, 2, stamper);
+    BSSM_STAMP(st, dbg, 2, FROM_LW ? 10 : 2, stamper);
     const uint64_t hb0 = d2b(a_in) & ~3ull;
     if (a_in == 0.0) {
         // exact incoming state (+0): resolve now and publish the exact outgoing state
@@ -916,7 +978,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
         if (bs.seg == 0) { mn[0] = lo_; mx[0] = hi_; } else { mn[1] = lo_; mx[1] = hi_; }   // no runtime index: keeps mn/mx in registers
     }
     block_minmax2(sm, mn, mx);
-    BSSM_STAMP(st, dbg, 2, 3, stamper);
+    BSSM_STAMP(st, dbg, 2, FROM_LW ? 11 : 3, stamper);
     // segment-0 prefix record: lanes [0, fb)
     if (bs.nb == 0) {
         if (t == NT - 1) {
@@ -1101,6 +1163,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     // ---- boundary walk.  One wave; lane j owns the j-th boundary block with its record in registers; the
     // exact state is handed from lane to lane by readlane, so each step costs one record evaluation. ----
     const int nent = nb * CB;
+    if (dbg0 == 99 && t == 0) { st->stamps[MODE][8] = nb; st->stamps[MODE][9] = B; }
     if (t < 64) {
         const int lane = t;
         const bool fits = (nb <= MAXBND) && (nent <= 64);
@@ -1130,11 +1193,13 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
         else {
             uint64_t s = 0, my_in = 0, my_out = 0;
             const bool special = (bidx >= 0) && (slow || nside == 1);
+            const StepFn fn = stepfn_build(ex, pr);          // "PURE run + this block's record" folded into constants
+            BSSM_STAMP(st, dbg0, MODE, 10, t == 0 && fn.mode >= 0);
             for (int j = 0; j < nent; j++) {
-                const uint64_t e = pure_step(ex, s);
-                uint64_t o = e;
-                bool ok = true;
-                if (bidx >= 0) o = rec_step(pr, e, ok);
+                bool ok;
+                uint64_t o = stepfn_apply(fn, s, ok);
+                const uint64_t e = pure_step(ex, s);         // (only lane j's copy is used)
+                if (bidx < 0) { o = e; ok = true; }
                 if (lane == j && (special || !ok)) {             // rare: side entry / tails / window miss
                     bool done = false;
                     if (!slow && ok && nside == 1) {
@@ -1162,6 +1227,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
                 const int olo = __builtin_amdgcn_readlane((int)(uint32_t)o, j), ohi = __builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), j);
                 s = ((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo;
             }
+            BSSM_STAMP(st, dbg0, MODE, 11, t == 0 && s != 1);
             if (lane == 0) sm.seg_start[0] = 0;
             if (have) {
                 if (bidx >= 0) cin[bidx] = my_in;                // boundary blocks are finished here
@@ -1244,8 +1310,6 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     __shared__ uint64_t tin[NT];
     __shared__ int Tl[EB];
     __shared__ int Tbegin;
-    constexpr int OWN_CAP = 6144;
-    __shared__ unsigned short own[OWN_CAP];
     const int t = threadIdx.x;
     const long long b0 = (long long)blockIdx.x * EB;
     // run-state words and this lane's terms are fetched together (one memory round trip, not two)
@@ -1254,9 +1318,29 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     const double total = b2d(st->total_bits);
     double v[EL];
     load_terms<MODE_W>(a.w, a.nw, 1.0, b0 + (long long)t * EL, v);
+    // this lane's own particles travel with its terms: the common expansion path stores them straight to the
+    // outputs their elements own, with no dependent gather
+    double xs0[EL], xs1[EL], axs[EL];
+#pragma unroll
+    for (int k = 0; k < EL; k++) { xs0[k] = 0.0; xs1[k] = 0.0; axs[k] = 0.0; }
+    if (KIND != 2) {
+        if (a.xdst) {
+            load_terms<MODE_W>(a.xsrc, a.nw, 1.0, b0 + (long long)t * EL, xs0);
+            if (a.dim > 1) {
+#pragma unroll
+                for (int k = 0; k < EL; k++) { const long long j = b0 + (long long)t * EL + k; xs1[k] = (j < a.nw) ? a.xsrc[a.xstride + j] : 0.0; }
+            }
+        }
+        if (a.auxdst) load_terms<MODE_W>(a.auxsrc, a.nw, 1.0, b0 + (long long)t * EL, axs);
+    }
     const double a_in_p = a.ain_p[blockIdx.x];
     const uint64_t cinb = a.cin[blockIdx.x];
     if (s_dead || !s_do || s_flags) return;
+    // the uniform(s) of this resample call (systematic: one draw; computed here, under the load latency)
+    UniformSrc us;
+    us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
+    us.key = a.key; us.call = (uint32_t)call;
+    const double Usys = (KIND == 1) ? us(0) : 0.0;
     const bool stamper = (t == 0 && blockIdx.x == (gridDim.x > 100 ? 100u : 0u));
     BSSM_STAMP(st, dbg, 3, 0, stamper);
 #pragma unroll
@@ -1271,10 +1355,7 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
     BSSM_STAMP(st, dbg, 3, 3, stamper);
     // the reference chain itself, from the exact incoming state
-    UniformSrc us;
-    us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
-    us.key = a.key; us.call = (uint32_t)call;
-    const double Usys = (KIND == 1) ? us(0) : 0.0;
+    int Tk[EL];
     double c = b2d(ent);
 #pragma unroll
     for (int k = 0; k < EL; k++) {
@@ -1287,6 +1368,7 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
         else if (KIND == 0) T = count_le_stratified(c, a.n, us);
         else T = 0;
         Tl[t * EL + k] = T;
+        Tk[k] = T;
     }
     if (KIND == 2) return;                                            // multinomial: k_multinomial searches cum_out
     BSSM_STAMP(st, dbg, 3, 4, stamper);
@@ -1303,56 +1385,33 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     int* anc = a.anc_out ? a.anc_out + (long long)call * a.anc_stride : nullptr;
     const double invN = 1.0 / (double)a.n;
     double acc0 = 0.0, acc1 = 0.0;
-    // Expansion.  Each element owns the outputs [T_prev, T) (src/resampling.cpp:30-37).  Common case (the
-    // block owns at most OWN_CAP outputs, no element more than 64): every lane writes the local index of
-    // its elements into the LDS slots of the outputs they own; the block then reads the slots back in
-    // output order, so the global gather/store is coalesced.  Otherwise: binary search in the counts.
-    const int nout = Te - Tb;
+    // Expansion.  Each element owns the outputs [T_prev, T) (src/resampling.cpp:30-37).  Common case (no element
+    // owns more than 64 outputs): every lane stores its own elements' particles straight to the outputs they own --
+    // consecutive lanes own consecutive output ranges, and nothing has to be gathered.  Otherwise (degenerate
+    // weights: a few particles own almost everything): all lanes share the work through a binary search in the counts.
     int tprev = (t == 0) ? Tb : Tl[t * EL - 1];
     int maxcnt = 0;
     {
         int p = tprev;
 #pragma unroll
-        for (int k = 0; k < EL; k++) { const int T = Tl[t * EL + k]; maxcnt = (T - p) > maxcnt ? (T - p) : maxcnt; p = T; }
+        for (int k = 0; k < EL; k++) { maxcnt = (Tk[k] - p) > maxcnt ? (Tk[k] - p) : maxcnt; p = Tk[k]; }
     }
     const int any_big = __syncthreads_or(maxcnt > 64);
-    if (nout <= OWN_CAP && !any_big) {
+    if (!any_big) {
         int p = tprev;
 #pragma unroll
         for (int k = 0; k < EL; k++) {
-            const int T = Tl[t * EL + k];
-            for (int i = p; i < T; i++) own[i - Tb] = (unsigned short)(t * EL + k);
+            const int T = Tk[k];
+            const long long src = b0 + (long long)t * EL + k;
+            for (int i = p; i < T; i++) {
+                if (anc) anc[i] = (int)(src + 1);                    // 1-based (src/resampling.cpp:36,62)
+                if (a.xdst) {
+                    a.xdst[i] = xs0[k]; acc0 += xs0[k] * invN;
+                    if (a.dim > 1) { a.xdst[a.xstride + i] = xs1[k]; acc1 += xs1[k] * invN; }
+                }
+                if (a.auxdst) a.auxdst[i] = axs[k];
+            }
             p = T;
-        }
-        __syncthreads();
-        // outputs in order, 8 per lane per round: all owner look-ups, then all gathers (independent loads in
-        // flight together), then the stores -- one memory round trip per round instead of one per output
-        for (int r0 = 0; r0 < nout; r0 += NT * EL) {
-            int lo[EL];
-            double x0[EL], x1[EL], ax[EL];
-#pragma unroll
-            for (int k = 0; k < EL; k++) { const int r = r0 + t + NT * k; lo[k] = (r < nout) ? (int)own[r] : -1; }
-#pragma unroll
-            for (int k = 0; k < EL; k++) {
-                x0[k] = 0.0; x1[k] = 0.0; ax[k] = 0.0;
-                if (lo[k] >= 0) {
-                    const long long src = b0 + lo[k];
-                    if (a.xdst) { x0[k] = a.xsrc[src]; if (a.dim > 1) x1[k] = a.xsrc[a.xstride + src]; }
-                    if (a.auxdst) ax[k] = a.auxsrc[src];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < EL; k++) {
-                if (lo[k] >= 0) {
-                    const int i = Tb + r0 + t + NT * k;
-                    if (anc) anc[i] = (int)(b0 + lo[k] + 1);         // 1-based (src/resampling.cpp:36,62)
-                    if (a.xdst) {
-                        a.xdst[i] = x0[k]; acc0 += x0[k] * invN;
-                        if (a.dim > 1) { a.xdst[a.xstride + i] = x1[k]; acc1 += x1[k] * invN; }
-                    }
-                    if (a.auxdst) a.auxdst[i] = ax[k];
-                }
-            }
         }
     } else {
         for (int i = Tb + t; i < Te; i += NT) {
