@@ -583,6 +583,19 @@ struct SegSmem {
 // composite of the PURE lanes between the previous boundary and this lane,
 // the lane's segment index (= number of boundaries before it), and leaves the
 // boundary count in sm.nb.
+// Inside the scan a PURE map travels as (d0, dd = d1 - d0): dd is tiny (it only moves at rounding ties) and is zero for
+// every lane of almost every wave, in which case the segmented scan degenerates to a segmented int64 add.
+//   compose(f, g):  a = odd(f.d0) ? g.dd : 0;  b = odd(f.d0 + f.dd + 1) ? g.dd : 0;
+//                   d0 = f.d0 + g.d0 + a;      dd = f.dd + b - a.
+struct PureC { int64_t d0; int32_t dd; };
+__device__ __forceinline__ PureC purec_compose(const PureC& f, const PureC& g)
+{
+    const int32_t a = (f.d0 & 1) ? g.dd : 0;
+    const int32_t b = ((f.d0 + f.dd + 1) & 1) ? g.dd : 0;
+    PureC c; c.d0 = f.d0 + g.d0 + a; c.dd = f.dd + b - a;
+    return c;
+}
+
 template <int NW>
 __device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, bool isb, int& seg, int& nb_total, Pure& block_incl_last_seg)
 {
@@ -590,45 +603,67 @@ __device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, boo
     const unsigned long long bal = __ballot(isb);
     const unsigned long long below = bal & ((1ull << lane) - 1ull);
     // head flag: the previous lane is a boundary (lane 0 of a wave: decided across waves)
-    Pure v; v.d0 = isb ? 0 : leaf.d0; v.d1 = isb ? 0 : leaf.d1;
+    PureC v; v.d0 = isb ? 0 : leaf.d0; v.dd = isb ? 0 : (int32_t)(leaf.d1 - leaf.d0);
     int fi = ((lane > 0) && ((bal >> (lane - 1)) & 1ull)) ? 1 : 0;
     // segmented inclusive scan: combine(prev, cur) = cur.f ? cur : (prev.v . cur.v, prev.f)
-#define STEP(C, R) { Pure pv; pv.d0 = dpp_i64<C, R>(0, v.d0); pv.d1 = dpp_i64<C, R>(0, v.d1); const int pf = dpp_i32<C, R>(0, fi); \
-                     if (!fi) { v = pure_compose(pv, v); fi = pf; } }
-    BSSM_WAVE_SCAN_STEPS(STEP)
+    if (__all(v.dd == 0)) {
+#define STEP(C, R) { const int64_t p0 = dpp_i64<C, R>(0, v.d0); const int pf = dpp_i32<C, R>(0, fi); if (!fi) { v.d0 += p0; fi = pf; } }
+        BSSM_WAVE_SCAN_STEPS(STEP)
 #undef STEP
+    } else {
+#define STEP(C, R) { PureC pv; pv.d0 = dpp_i64<C, R>(0, v.d0); pv.dd = dpp_i32<C, R>(0, v.dd); const int pf = dpp_i32<C, R>(0, fi); \
+                     if (!fi) { v = purec_compose(pv, v); fi = pf; } }
+        BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
+    }
     // v = composite from the segment head (or the wave start) up to and including this lane
     const bool last_is_b = (bal >> 63) & 1ull;
     if (lane == 63) {
-        Pure a = v;
+        Pure a; a.d0 = v.d0; a.d1 = v.d0 + v.dd;
         if (last_is_b) { a.d0 = 0; a.d1 = 0; }                        // a boundary in the last lane: nothing is carried
         sm.wagg[wave] = a; sm.wflag[wave] = (bal != 0ull) ? 1 : 0;    // a boundary anywhere in the wave cuts the carry
         sm.wnb[wave] = __popcll(bal);
     }
     __syncthreads();
-    // carries across waves: wave 0 scans the NW wave aggregates (segmented) and publishes exclusive carries
-    if (wave == 0) {
-        Pure a; a.d0 = 0; a.d1 = 0; int af = 0, an = 0;
-        if (lane < NW) { a = sm.wagg[lane]; af = sm.wflag[lane]; an = sm.wnb[lane]; }
-        int cn = an;
+    Pure carry; carry.d0 = 0; carry.d1 = 0;
+    int segbase = 0;
+    if (NW <= 4) {
+        // few waves: every lane folds the aggregates of the waves before its own
+        Pure all; all.d0 = 0; all.d1 = 0;
+        int nball = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if (w == wave) { carry = all; segbase = nball; }
+            if (sm.wflag[w]) all = sm.wagg[w]; else all = pure_compose(all, sm.wagg[w]);
+            nball += sm.wnb[w];
+        }
+        nb_total = nball;
+        block_incl_last_seg = all;
+    } else {
+        // many waves (the resolve workgroup): wave 0 scans the NW aggregates and publishes exclusive carries
+        if (wave == 0) {
+            Pure a; a.d0 = 0; a.d1 = 0; int af = 0, an = 0;
+            if (lane < NW) { a = sm.wagg[lane]; af = sm.wflag[lane]; an = sm.wnb[lane]; }
+            int cn = an;
 #define STEP(C, R) { Pure pv; pv.d0 = dpp_i64<C, R>(0, a.d0); pv.d1 = dpp_i64<C, R>(0, a.d1); const int pf = dpp_i32<C, R>(0, af); \
                      cn += dpp_i32<C, R>(0, cn); if (!af) { a = pure_compose(pv, a); af = pf; } }
-        STEP(DPP_SHR1, 0xf) STEP(DPP_SHR2, 0xf) STEP(DPP_SHR4, 0xf) STEP(DPP_SHR8, 0xf)
+            STEP(DPP_SHR1, 0xf) STEP(DPP_SHR2, 0xf) STEP(DPP_SHR4, 0xf) STEP(DPP_SHR8, 0xf)
 #undef STEP
-        // inclusive over waves 0..lane; exclusive = previous lane's
-        Pure e; e.d0 = dpp_i64<DPP_WAVE_SHR1, 0xf>(0, a.d0); e.d1 = dpp_i64<DPP_WAVE_SHR1, 0xf>(0, a.d1);
-        const int en = dpp_i32<DPP_WAVE_SHR1, 0xf>(0, cn);
-        if (lane < NW) { sm.wcarry[lane] = e; sm.wsegbase[lane] = en; }
-        if (lane == NW - 1) { sm.wcarry[NW] = a; sm.wsegbase[NW] = cn; }
+            Pure e; e.d0 = dpp_i64<DPP_WAVE_SHR1, 0xf>(0, a.d0); e.d1 = dpp_i64<DPP_WAVE_SHR1, 0xf>(0, a.d1);
+            const int en = dpp_i32<DPP_WAVE_SHR1, 0xf>(0, cn);
+            if (lane < NW) { sm.wcarry[lane] = e; sm.wsegbase[lane] = en; }
+            if (lane == NW - 1) { sm.wcarry[NW] = a; sm.wsegbase[NW] = cn; }
+        }
+        __syncthreads();
+        carry = sm.wcarry[wave];
+        segbase = sm.wsegbase[wave];
+        nb_total = sm.wsegbase[NW];
+        block_incl_last_seg = sm.wcarry[NW];
     }
-    __syncthreads();
-    const Pure carry = sm.wcarry[wave];
-    const int segbase = sm.wsegbase[wave];
-    nb_total = sm.wsegbase[NW];
-    block_incl_last_seg = sm.wcarry[NW];
     // lanes at or before the first boundary of the wave (inclusive of that boundary lane) still belong to the carried segment
     const bool carried = (below == 0ull);
-    const Pure inc = carried ? pure_compose(carry, v) : v;
+    Pure vi; vi.d0 = v.d0; vi.d1 = v.d0 + v.dd;
+    const Pure inc = carried ? pure_compose(carry, vi) : vi;
     // exclusive = inclusive of the previous lane, unless the previous lane is a boundary
     Pure exc; exc.d0 = dpp_i64<DPP_WAVE_SHR1, 0xf>(carry.d0, inc.d0); exc.d1 = dpp_i64<DPP_WAVE_SHR1, 0xf>(carry.d1, inc.d1);
     if (lane > 0 && ((bal >> (lane - 1)) & 1ull)) { exc.d0 = 0; exc.d1 = 0; }

@@ -269,3 +269,48 @@ def test_pmmh_concurrent_chains_match_sequential(B, ctx):
         b2 = B.pmmh(chains_per_gpu=3, **kw)
     for k in ("chain", "phi", "sigma_x", "sigma_y"):
         assert (a["theta_chain"][k] == b2["theta_chain"][k]).all()
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 63, 65, 257, 2047, 2049, 4099])
+def test_ragged_particle_counts(B, ctx, oracle, N):
+    """Odd / tiny / block-straddling particle counts (the reference's tests run N = 20..100)."""
+    rng = np.random.default_rng(N)
+    T = 8
+    ys = _simulate(rng, T)
+    m = B.models.linear_gaussian()
+    for rf in ("stratified", "systematic"):
+        d = _draws(rng, oracle, "BPF", T, N, rf)
+        res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_fn=rf,
+                                 resample_algorithm="SISR", draws=d, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
+        ref = oracle.pf_run("lg", (0.8, 1.0, 1.0), ys, N, d["z_init"], d["z_trans"], d["u_res"], resample_fn=rf,
+                            resample_algorithm="SISR")
+        _compare(res, ref, N)
+
+
+def test_empty_series_and_single_obs(B, ctx, oracle):
+    m = B.models.linear_gaussian()
+    rng = np.random.default_rng(0)
+    r0 = B.bootstrap_filter([], 100, m.init_fn, m.transition_fn, m.log_likelihood_fn, ctx=ctx, seed=1,
+                            phi=0.8, sigma_x=1.0, sigma_y=1.0)
+    assert r0["loglike"] == 0.0 and len(r0["state_est"]) == 1 and len(r0["loglike_history"]) == 0
+    assert r0["ess"][0] == pytest.approx(100, rel=1e-12)
+    d = _draws(rng, oracle, "BPF", 1, 100, "stratified")
+    r1 = B.bootstrap_filter([0.3], 100, m.init_fn, m.transition_fn, m.log_likelihood_fn, draws=d, ctx=ctx,
+                            phi=0.8, sigma_x=1.0, sigma_y=1.0)
+    ref = oracle.pf_run("lg", (0.8, 1.0, 1.0), [0.3], 100, d["z_init"], d["z_trans"], d["u_res"])
+    _compare(r1, ref, 100)
+
+
+def test_threshold_argument(B, ctx, oracle):
+    """explicit threshold (R/particle_filter_core.R:44-50: auto only when NULL)"""
+    rng = np.random.default_rng(21)
+    T, N = 15, 1500
+    ys = _simulate(rng, T)
+    m = B.models.linear_gaussian()
+    d = _draws(rng, oracle, "BPF", T, N, "systematic")
+    for thr in (0.0, 0.9 * N, 10.0 * N):
+        res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_fn="systematic",
+                                 threshold=thr, draws=d, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
+        ref = oracle.pf_run("lg", (0.8, 1.0, 1.0), ys, N, d["z_init"], d["z_trans"], d["u_res"],
+                            resample_fn="systematic", threshold=thr)
+        _compare(res, ref, N)

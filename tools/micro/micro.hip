@@ -1,0 +1,49 @@
+// Dev tool: cycle costs of the primitives the scan kernels are made of (clock64 deltas, one workgroup of 256).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../bayesssm_amd/csrc/kernels.hip.h"
+using namespace bssm;
+
+__global__ void k(long long* out, const double* g, double* sink, int reps)
+{
+    __shared__ double lds[4096];
+    __shared__ double sh4[16];
+    const int t = threadIdx.x;
+    double x = g[t];
+    long long c0, c1;
+    int slot = 0;
+#define MEASURE(body) { __syncthreads(); c0 = clock64(); for (int r = 0; r < reps; r++) { body; } c1 = clock64(); if (t == 0) out[slot] = (c1 - c0) / reps; slot++; }
+    MEASURE(__syncthreads())                                                          // 0 barrier
+    MEASURE(x = wave_incl_sum(x))                                                     // 1 DPP inclusive scan f64
+    MEASURE(x = block_excl_scan(x, sh4))                                              // 2 block excl scan (2 barriers)
+    MEASURE(lds[t] = x; __syncthreads(); x = lds[(t + 17) & 255] + 1.0; __syncthreads()) // 3 LDS write+barrier+read+barrier
+    MEASURE(x = exp(x * 1e-3) )                                                       // 4 exp
+    MEASURE(x = x / (1.0 + x * 1e-9))                                                 // 5 division
+    MEASURE(x = log(fabs(x) + 1.5))                                                   // 6 log
+    MEASURE(x = g[(t * 64 + (int)(x * 1e-30) + r * 4096) & 0xFFFFF] + x)              // 7 dependent global load (L2/MALL)
+    MEASURE(x = block_sum(x, sh4) * 1e-3)                                             // 8 block_sum
+    { Pure p; p.d0 = (int64_t)x; p.d1 = p.d0 + 1; int seg, nb; Pure last; __shared__ SegSmem sm;
+      MEASURE(p = seg_excl_scan<4>(sm, p, (t & 63) == 17, seg, nb, last); p.d1 += seg) // 9 segmented record scan
+      x += (double)p.d0; }
+    { double v[8]; for (int k2 = 0; k2 < 8; k2++) v[k2] = x * 1e-6 + k2 * 1e-7; Rec rr;
+      MEASURE(rr = chunk_record_fixed<8>(v, 0.4 + x * 1e-12, 1000); v[0] += (double)(rr.o[0] & 1) * 1e-9) // 10 chunk record
+      x += v[0]; }
+    { double u1, u2; PhiloxKey key{1, 2, 3};
+      MEASURE(normal_pair(key, 2, r, 0, t, u1, u2); x += u1 * 1e-9 + u2 * 1e-9) }     // 11 philox + box-muller pair
+    sink[t] = x;
+}
+
+int main()
+{
+    long long* out; double *g, *sink;
+    hipMalloc(&out, 64 * 8); hipMalloc(&g, (1 << 20) * 8); hipMalloc(&sink, 256 * 8);
+    hipMemset(g, 0, (1 << 20) * 8); hipMemset(out, 0, 64 * 8);
+    for (int it = 0; it < 2; it++) hipLaunchKernelGGL(k, dim3(1), dim3(256), 0, 0, out, g, sink, 50);
+    hipDeviceSynchronize();
+    long long h[64]; hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost);
+    const char* names[] = {"barrier", "wave DPP incl scan f64", "block_excl_scan", "LDS wr+bar+rd+bar", "exp", "div", "log",
+                           "dependent global load", "block_sum", "seg_excl_scan<4>", "chunk_record<8>", "philox+box-muller pair"};
+    for (int i = 0; i < 12; i++) printf("%-28s %6lld cycles\n", names[i], h[i]);
+    return 0;
+}
