@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libbayesssm_amd.so")
 
 OK, ERR_NEGATIVE, ERR_ZERO_SUM, ERR_LENGTH, ERR_ARG, ERR_HIP, ERR_CAPACITY = range(7)
 MODEL = {"lg": 0, "ar1sin": 1, "sir": 2}
-ALGORITHM = {"BPF": 0, "APF": 1}
+ALGORITHM = {"BPF": 0, "APF": 1, "RMPF": 2}
 RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
 RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2}
 TRANSFORM = {"identity": 0, "log": 1, "logit": 2}
@@ -32,6 +32,7 @@ class PfConfig(C.Structure):
         ("seed", C.c_ulonglong), ("stream", C.c_ulonglong),
         ("z_init", C.c_void_p), ("z_trans", C.c_void_p), ("u_res", C.c_void_p),
         ("return_particles", C.c_int), ("return_ancestors", C.c_int),
+        ("move_sd", C.c_double), ("z_move", C.c_void_p), ("u_move", C.c_void_p),
     ]
 
 
@@ -97,6 +98,7 @@ def load():
     lib.bssm_pf_noise_shape.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.bssm_dump_normals.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_int, C.c_longlong, C.c_void_p]
     lib.bssm_dump_uniforms.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_longlong, C.c_void_p]
+    lib.bssm_dump_move_draws.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
     lib.bssm_pmmh_chain.argtypes = [C.c_void_p, C.POINTER(PmmhConfig), C.POINTER(PmmhResult)]
     _lib = lib
     return lib
@@ -106,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "bssm_ctx_create", "bssm_ctx_destroy", "bssm_last_error", "bssm_status_string", "bssm_device_count",
     "bssm_ctx_synchronize", "bssm_ctx_stream", "bssm_resample_systematic", "bssm_resample_stratified",
     "bssm_resample_multinomial", "bssm_resample_device", "bssm_resample_device_status", "bssm_resample_ex",
-    "bssm_pf_run", "bssm_pf_noise_shape", "bssm_dump_normals", "bssm_dump_uniforms",
+    "bssm_pf_run", "bssm_pf_noise_shape", "bssm_dump_normals", "bssm_dump_uniforms", "bssm_dump_move_draws",
     "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_pmmh_chain",
 ]
 

@@ -390,6 +390,21 @@ extern "C" int bssm_dump_normals(bssm_ctx* c, unsigned long long seed, unsigned 
     HIPCHK(hipStreamSynchronize(c->stream));
     return BSSM_OK;
 }
+extern "C" int bssm_dump_move_draws(bssm_ctx* c, unsigned long long seed, unsigned long long stream, int call, long long n,
+                                    double* z_out, double* u_out)
+{
+    if (!c || !z_out || !u_out || n <= 0) ARGFAIL("bssm_dump_move_draws: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    void *dz, *du; int rc;
+    if ((rc = pool_get(c, "dump", (size_t)n * 8, &dz))) return rc;
+    if ((rc = pool_get(c, "dump2", (size_t)n * 8, &du))) return rc;
+    hipLaunchKernelGGL(k_dump_move, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, make_key(seed, stream), (uint32_t)call, n, (double*)dz, (double*)du);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(z_out, dz, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(u_out, du, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BSSM_OK;
+}
 extern "C" int bssm_dump_uniforms(bssm_ctx* c, unsigned long long seed, unsigned long long stream, int call, long long n, double* out)
 {
     if (!c || !out || n <= 0) ARGFAIL("bssm_dump_uniforms: bad argument");
@@ -460,7 +475,11 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     if (sir && (cfg->z_init || cfg->z_trans)) ARGFAIL("bssm_pf_run: the SIR model draws a data-dependent number of variates; injected z_* are not supported");
     if (sir && cfg->n_theta < 5) ARGFAIL("bssm_pf_run: SIR theta must hold (lambda, gamma, n_total, s0, i0)");
     if (sir && c->max_dim < 2) { g_err = "bssm_pf_run: the SIR model needs a context created with max_dim = 2"; return BSSM_ERR_CAPACITY; }
-    if (cfg->algorithm != BSSM_BPF && cfg->algorithm != BSSM_APF) ARGFAIL("bssm_pf_run: unknown algorithm");
+    if (cfg->algorithm != BSSM_BPF && cfg->algorithm != BSSM_APF && cfg->algorithm != BSSM_RMPF) ARGFAIL("bssm_pf_run: unknown algorithm");
+    const bool rmpf = cfg->algorithm == BSSM_RMPF;
+    if (rmpf && cfg->model == BSSM_MODEL_SIR) ARGFAIL("bssm_pf_run: the built-in move step is defined for the scalar Gaussian-observation models only");
+    if (rmpf && !(cfg->move_sd > 0)) ARGFAIL("bssm_pf_run: RMPF needs move_sd > 0");
+    if (rmpf && ((cfg->z_move == nullptr) != (cfg->u_move == nullptr))) ARGFAIL("bssm_pf_run: z_move and u_move must be given together");
     if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run: unknown resample_algorithm");
     if (cfg->resample_fn < 0 || cfg->resample_fn > 2) ARGFAIL("bssm_pf_run: unknown resample_fn");
     if (!cfg->theta || cfg->n_theta < 3) ARGFAIL("bssm_pf_run: theta must hold (phi, sigma_x, sigma_y) or (lambda, gamma, n_total, s0, i0)");
@@ -475,9 +494,11 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     const int dim = sir ? 2 : 1;
     const int B = (int)((N + EB - 1) / EB);
     const bool apf = cfg->algorithm == BSSM_APF;
+    (void)rmpf;
     const double dN = (double)N;
-    double threshold = cfg->threshold;
-    if (threshold < 0) threshold = (cfg->resample_algorithm == BSSM_SIS) ? INFINITY : (cfg->resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
+    const int resample_algorithm = rmpf ? BSSM_SISR : cfg->resample_algorithm;     // RMPF forces SISR (R/resample_move_filter.R:229)
+    double threshold = rmpf ? -1.0 : cfg->threshold;
+    if (threshold < 0) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
     int max_trans = 0, max_res = 0;
     bssm_pf_noise_shape(cfg->algorithm, T, cfg->obs_times, &max_trans, &max_res);
     const long long u_stride = (cfg->resample_fn == BSSM_SYSTEMATIC) ? 1 : N;
@@ -499,6 +520,13 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     }
     if (cfg->z_init) { if ((rc = pool_get(c, "zi", (size_t)N * 8, &d_zi))) return rc; HIPCHK(hipMemcpyAsync(d_zi, cfg->z_init, (size_t)N * 8, hipMemcpyHostToDevice, c->stream)); }
     if (cfg->z_trans && max_trans > 0) { if ((rc = pool_get(c, "zt", (size_t)max_trans * N * 8, &d_zt))) return rc; HIPCHK(hipMemcpyAsync(d_zt, cfg->z_trans, (size_t)max_trans * N * 8, hipMemcpyHostToDevice, c->stream)); }
+    void *d_zmv = nullptr, *d_umv = nullptr;
+    if (rmpf && cfg->z_move && T > 0) {
+        if ((rc = pool_get(c, "zmv", (size_t)T * N * 8, &d_zmv))) return rc;
+        if ((rc = pool_get(c, "umv", (size_t)T * N * 8, &d_umv))) return rc;
+        HIPCHK(hipMemcpyAsync(d_zmv, cfg->z_move, (size_t)T * N * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_umv, cfg->u_move, (size_t)T * N * 8, hipMemcpyHostToDevice, c->stream));
+    }
     if (cfg->u_res && max_res > 0) { if ((rc = pool_get(c, "ur", (size_t)max_res * u_stride * 8, &d_ur))) return rc; HIPCHK(hipMemcpyAsync(d_ur, cfg->u_res, (size_t)max_res * u_stride * 8, hipMemcpyHostToDevice, c->stream)); }
     HIPCHK(hipMemsetAsync(d_separt, 0, (size_t)(T + 1) * B * dim * 8, c->stream));
     HIPCHK(hipMemsetAsync(d_ess, 0, (size_t)(T + 1) * 8, c->stream));
@@ -561,13 +589,19 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         }
         double* se_row = separt + (size_t)i * B * dim;
         // normalise (:204-207) + loglik/ESS/decision (:208-218) + resample (:220-224), fused into the scan kernels
-        r.d_lw = c->lw; r.plan = PLAN_PF; r.check_degenerate = 1; r.obs_i = i; r.resample_algorithm = cfg->resample_algorithm;
+        r.d_lw = c->lw; r.plan = PLAN_PF; r.check_degenerate = 1; r.obs_i = i; r.resample_algorithm = resample_algorithm;
         r.threshold = threshold; r.d_ess = (double*)d_ess; r.d_llh = (double*)d_llh; r.d_resampled = (int*)d_resampled;
         r.xsrc = X0; r.xdst = X1; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = se_row;
         launch_scan_and_apply(c, r);
-        if (cfg->resample_algorithm != BSSM_SISR)
+        if (resample_algorithm != BSSM_SISR)
             LAUNCH(c, "k_carry", k_carry, B, NT, 0, X0, X1, c->w, N, dim, se_row, c->st);
         std::swap(X0, X1);
+        if (rmpf) {   // move every particle, then take the state estimate (:226-241)
+            const double* zm = d_zmv ? (const double*)d_zmv + (size_t)(i - 1) * N : nullptr;
+            const double* um = d_umv ? (const double*)d_umv + (size_t)(i - 1) * N : nullptr;
+            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_move", k_move<0>, B, NT, 0, X0, N, par, yi, cfg->move_sd, zm, um, key, (uint32_t)i, se_row, c->st);
+            else LAUNCH(c, "k_move", k_move<1>, B, NT, 0, X0, N, par, yi, cfg->move_sd, zm, um, key, (uint32_t)i, se_row, c->st);
+        }
         if (cfg->return_particles) {
             LAUNCH(c, "k_record_history", k_record_history, (unsigned)((N + 255) / 256), 256, 0, X0, c->w, N, dim,
                    (double*)d_ph + (size_t)i * N * dim, (double*)d_wh + (size_t)i * N, c->st);

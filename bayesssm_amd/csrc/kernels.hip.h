@@ -1513,6 +1513,49 @@ __global__ __launch_bounds__(NT) void k_multinomial(const double* __restrict__ c
     }
 }
 
+// resample_move_filter's move step (R/particle_filter_core.R:226-234) for the built-in random-walk Metropolis move
+// of the reference's own example (R/resample_move_filter.R:166-176, tests/testthat/test-resample_move_filter.R:26-35):
+//   proposal = particle + rnorm(1, 0, sd);  accept if log(runif(1)) < loglik(proposal) - loglik(particle).
+// Also the state-estimate partials, which the core takes AFTER the move (:237-241).
+template <int MODEL>
+__global__ __launch_bounds__(NT) void k_move(double* __restrict__ x, long long N, ModelPar par, double y, double move_sd,
+                                             const double* __restrict__ zmv, const double* __restrict__ umv,
+                                             PhiloxKey key, uint32_t call, double* __restrict__ se_part,
+                                             const DevState* __restrict__ st)
+{
+    if (st->dead) return;
+    __shared__ double sh4[4];
+    const long long base = (long long)blockIdx.x * EB;
+    const double invN = 1.0 / (double)N;
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < EL; r++) {
+        const long long j = base + threadIdx.x + NT * r;
+        if (j < N) {
+            double z, u;
+            if (zmv) { z = zmv[j]; u = umv[j]; } else move_draws(key, call, (uint32_t)j, z, u);
+            const double cur = x[j];
+            const double prop = cur + r_rnorm(0.0, move_sd, z);
+            const double lp_cur = r_dnorm_log(y, cur, par.sy, par.log_sy);
+            const double lp_prop = r_dnorm_log(y, prop, par.sy, par.log_sy);
+            const double out = (log(u) < (lp_prop - lp_cur)) ? prop : cur;
+            x[j] = out;
+            acc += out * invN;
+        }
+    }
+    acc = block_sum(acc, sh4);
+    if (threadIdx.x == 0) se_part[blockIdx.x] = acc;
+}
+
+__global__ void k_dump_move(PhiloxKey key, uint32_t call, long long n, double* __restrict__ zout, double* __restrict__ uout)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double z, u;
+    move_draws(key, call, (uint32_t)i, z, u);
+    zout[i] = z; uout[i] = u;
+}
+
 // no resampling at this observation: particles carry over; state estimate is
 // sum(particles * weights) with the normalised weights (:238)
 __global__ __launch_bounds__(NT) void k_carry(const double* __restrict__ xsrc, double* __restrict__ xdst,

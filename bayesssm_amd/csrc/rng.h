@@ -27,7 +27,7 @@
 
 namespace bssm {
 
-enum : uint32_t { DRAW_INIT = 1, DRAW_TRANS = 2, DRAW_RESAMPLE = 3, DRAW_PROPOSAL = 5, DRAW_ACCEPT = 6 };
+enum : uint32_t { DRAW_INIT = 1, DRAW_TRANS = 2, DRAW_RESAMPLE = 3, DRAW_PROPOSAL = 5, DRAW_ACCEPT = 6, DRAW_MOVE = 7 };
 
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -123,6 +123,15 @@ BSSM_HD double resample_uniform(PhiloxKey key, uint32_t call, uint32_t i)
     u32x4 c; c.x = i >> 1; c.y = call; c.z = DRAW_RESAMPLE; c.w = key.stream;
     const u32x4 r = philox4x32_10(c, key.k0, key.k1);
     return (i & 1) ? u01_from_bits(r.z, r.w) : u01_from_bits(r.x, r.y);
+}
+
+// One (normal, uniform) pair for the resample-move step of particle i at observation `call`.
+BSSM_HD void move_draws(PhiloxKey key, uint32_t call, uint32_t i, double& z, double& u)
+{
+    u32x4 c; c.x = i; c.y = call; c.z = DRAW_MOVE; c.w = key.stream;
+    const u32x4 r = philox4x32_10(c, key.k0, key.k1);
+    z = qnorm_as241(u01_from_bits(r.x, r.y));
+    u = u01_from_bits(r.z, r.w);
 }
 
 }  // namespace bssm

@@ -32,7 +32,8 @@ def noise_shape(algorithm, T, obs_times=None):
 
 def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_times=None,
                          resample_algorithm="SISAR", resample_fn="stratified", threshold=None,
-                         return_particles=True, return_ancestors=False, seed=0, stream=0, draws=None, ctx=None):
+                         return_particles=True, return_ancestors=False, seed=0, stream=0, draws=None, ctx=None,
+                         move_sd=0.0):
     """.particle_filter_core on the device.  `draws` (parity mode) = dict(z_init, z_trans, u_res)
     of injected random draws; otherwise the device generator keyed by (seed, stream) is used."""
     if not (isinstance(num_particles, (int, np.integer)) and num_particles > 0):
@@ -75,10 +76,16 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
             zi = np.ascontiguousarray(draws["z_init"], dtype=np.float64)
             zt = np.ascontiguousarray(draws["z_trans"], dtype=np.float64)
             assert zi.size >= N and zt.size >= max_trans * N
+    zmv = umv = None
+    if draws is not None and algorithm == "RMPF":
+        zmv = np.ascontiguousarray(draws["z_move"], dtype=np.float64)
+        umv = np.ascontiguousarray(draws["u_move"], dtype=np.float64)
+        assert zmv.size >= T * N and umv.size >= T * N
     cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
                         _lib.RESAMPLE_FN[resample_fn], N, T, -1.0 if threshold is None else float(threshold),
                         _ptr(theta), int(theta.size), _ptr(y), _ptr(ot), int(seed), int(stream),
-                        _ptr(zi), _ptr(zt), _ptr(ur), 1 if return_particles else 0, 1 if return_ancestors else 0)
+                        _ptr(zi), _ptr(zt), _ptr(ur), 1 if return_particles else 0, 1 if return_ancestors else 0,
+                        float(move_sd), _ptr(zmv), _ptr(umv))
     res = _lib.PfResult(_ptr(state_est), _ptr(ess), _ptr(llh), _ptr(ll), _ptr(ers), _ptr(nres), _ptr(resampled),
                         _ptr(anc), _ptr(ph), _ptr(wh), _ptr(ms), _ptr(scan_stats))
     st = _lib.load().bssm_pf_run(ctx.handle, C.byref(cfg), C.byref(res))
@@ -89,7 +96,7 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
            "algorithm": algorithm}
     early = int(ers[0])
     if early == 0:
-        out["resample_algorithm"] = resample_algorithm        # absent on the degenerate early return (:192-196)
+        out["resample_algorithm"] = "SISR" if algorithm == "RMPF" else resample_algorithm   # absent on the early return (:192-196)
     if return_particles:
         rows = early if early else T + 1                      # histories end where the reference returned
         out["particles_history"] = ph[:rows]
@@ -129,6 +136,24 @@ def auxiliary_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
                                 threshold, return_particles, **ctl)
 
 
+def resample_move_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn, move_fn, obs_times=None,
+                         resample_fn=None, return_particles=True, **kwargs):
+    """resample_move_filter (R/resample_move_filter.R:190-236): resample at every step (SISR), then move every
+    particle.  `move_fn` must be the built-in random-walk Metropolis move (`model.rw_move_fn(sd)`), the move of the
+    reference's own example; arbitrary R closures cannot run on the device."""
+    resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    kwargs.pop("resample_algorithm", None)                    # removed from ... by the reference too (:213-216)
+    ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
+    if not isinstance(move_fn, models.MoveFn):
+        raise TypeError("move_fn must be a built-in move descriptor (model.rw_move_fn(sd))")
+    model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
+    if move_fn.model != model or model == "sir":
+        raise ValueError("move_fn belongs to a different model")
+    theta = models.theta_from_kwargs((init_fn, transition_fn, log_likelihood_fn), kwargs)
+    return particle_filter_core(y, num_particles, model, theta, "RMPF", obs_times, "SISR", resample_fn, None,
+                                return_particles, move_sd=move_fn.sd, **ctl)
+
+
 def dump_draws(algorithm, T, N, resample_fn, seed, stream, obs_times=None, ctx=None):
     """The device generator's draws for one filter run, as arrays a CPU run can consume
     (same layout as the `draws` argument)."""
@@ -144,4 +169,10 @@ def dump_draws(algorithm, T, N, resample_fn, seed, stream, obs_times=None, ctx=N
     ur = np.empty((max(max_res, 1), nu))
     for k in range(max_res):
         _lib.check(lib.bssm_dump_uniforms(ctx.handle, seed, stream, k, nu, _ptr(ur[k])))
-    return {"z_init": zi, "z_trans": zt, "u_res": ur.reshape(-1) if nu == 1 else ur}
+    out = {"z_init": zi, "z_trans": zt, "u_res": ur.reshape(-1) if nu == 1 else ur}
+    if algorithm == "RMPF":
+        zm, um = np.empty((max(T, 1), N)), np.empty((max(T, 1), N))
+        for i in range(T):
+            _lib.check(lib.bssm_dump_move_draws(ctx.handle, seed, stream, i + 1, N, _ptr(zm[i]), _ptr(um[i])))
+        out["z_move"], out["u_move"] = zm, um
+    return out

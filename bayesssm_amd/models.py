@@ -40,6 +40,9 @@ class Model:
         self.param_order = self.PARAM_ORDER
         self.constants = ()
 
+    def rw_move_fn(self, sd=0.1):
+        return MoveFn(self.name, sd)
+
 
 class SirModel(Model):
     """Stochastic SIR of vignettes/articles/stochastic-sir-model.Rmd:143-176,285-310: state (s, i), one Gillespie
@@ -63,6 +66,18 @@ class SirModel(Model):
 
 def sir(n_total=500, init_infected=70):
     return SirModel(n_total, init_infected)
+
+
+class MoveFn:
+    """Built-in move_fn of resample_move_filter: the random-walk Metropolis move of the reference's own example
+    (R/resample_move_filter.R:166-176):  proposal = particle + rnorm(1, 0, sd);  accept when
+    log(runif(1)) < log_likelihood(proposal) - log_likelihood(particle)."""
+
+    def __init__(self, model, sd=0.1):
+        self.model, self.sd = model, float(sd)
+
+    def formals(self):
+        return ["particle", "y", "sigma_y"]
 
 
 def linear_gaussian():

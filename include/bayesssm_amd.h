@@ -53,6 +53,7 @@ extern "C" {
 
 #define BSSM_BPF 0            /* bootstrap_filter  */
 #define BSSM_APF 1            /* auxiliary_filter  */
+#define BSSM_RMPF 2           /* resample_move_filter with the built-in random-walk Metropolis move (R/resample_move_filter.R:166-176) */
 
 #define BSSM_SIS 0
 #define BSSM_SISR 1
@@ -138,6 +139,10 @@ typedef struct {
     const double* u_res;     /* systematic [n_res_calls]; else [n_res_calls][N] */
     int return_particles;    /* fill particles_history / weights_history       */
     int return_ancestors;    /* fill ancestors                                 */
+    /* BSSM_RMPF only: proposal sd of the move, and (parity mode) its injected draws [T][N] each */
+    double move_sd;
+    const double* z_move;
+    const double* u_move;
 } bssm_pf_config;
 
 typedef struct {
@@ -167,6 +172,8 @@ int bssm_dump_normals(bssm_ctx* ctx, unsigned long long seed, unsigned long long
                       int purpose /* 1 init, 2 transition */, int call, long long n, double* out);
 int bssm_dump_uniforms(bssm_ctx* ctx, unsigned long long seed, unsigned long long stream,
                        int call, long long n, double* out);
+int bssm_dump_move_draws(bssm_ctx* ctx, unsigned long long seed, unsigned long long stream,
+                         int call, long long n, double* z_out, double* u_out);
 
 /* Per-kernel-class device time of the last bssm_pf_run with profiling enabled
  * (bssm_ctx_set_profile(ctx, 1) inserts HIP events around every launch; slower,

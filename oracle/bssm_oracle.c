@@ -42,7 +42,7 @@
 #define ORC_LN_SQRT_2PI 0.918938533204672741780329736406
 
 enum { ORC_MODEL_LG = 0, ORC_MODEL_AR1SIN = 1, ORC_MODEL_SIR = 2 };
-enum { ORC_BPF = 0, ORC_APF = 1 };
+enum { ORC_BPF = 0, ORC_APF = 1, ORC_RMPF = 2 };
 enum { ORC_SIS = 0, ORC_SISR = 1, ORC_SISAR = 2 };
 enum { ORC_STRATIFIED = 0, ORC_SYSTEMATIC = 1, ORC_MULTINOMIAL = 2 };
 
@@ -316,6 +316,10 @@ typedef struct {
     int *n_res_calls;       /* [1] out */
     int *early_return_step; /* [1] out: 0 = ran to the end; i>0 = degenerate at obs i (:189-202) */
     int *resampled;         /* optional [T]: 1 if the weight-triggered resample ran at obs i */
+    /* RMPF (R/resample_move_filter.R): the random-walk Metropolis move of the reference's example (:166-176) */
+    double move_sd;
+    const double *z_move;   /* [T][N]: the rnorm(1, 0, sd) draw of each particle's move */
+    const double *u_move;   /* [T][N]: its runif(1) draw */
 } orc_pf_args;
 
 /* R sum(): long double accumulator (R summary.c rsum), rounded once. */
@@ -440,6 +444,7 @@ int orc_pf_run(orc_pf_args *a)
 
         int should = (a->resample_algorithm == ORC_SIS) ? 0
                    : (a->resample_algorithm == ORC_SISR) ? 1 : (ess < threshold);   /* :214-218 */
+        if (a->algorithm == ORC_RMPF) should = 1;            /* algorithm == "RMPF" || should_resample :220 */
         if (a->resampled) a->resampled[i - 1] = should;
         if (should) {                                         /* :220-224 */
             rc = orc_resample_dispatch(a->resample_fn, N, w,
@@ -451,6 +456,15 @@ int orc_pf_run(orc_pf_args *a)
             for (int d = 0; d < D; d++) for (int k = 0; k < N; k++) x[(size_t)d * N + k] = xold[(size_t)d * N + idx[k] - 1];   /* R/resampling.R:40,60 */
             for (int k = 0; k < N; k++) w[k] = 1.0 / dN;
             a->ess[i] = dN;                                   /* :223 */
+        }
+        if (a->algorithm == ORC_RMPF) {                      /* :226-234, move_fn of R/resample_move_filter.R:166-176 */
+            const double sy = a->theta[2], log_sy = log(sy);
+            for (int k = 0; k < N; k++) {
+                double cur = x[k];
+                double prop = cur + orc_rnorm(0.0, a->move_sd, a->z_move[(size_t)(i - 1) * N + k]);
+                double lp_cur = orc_dnorm_log(yi, cur, sy, log_sy), lp_prop = orc_dnorm_log(yi, prop, sy, log_sy);
+                if (log(a->u_move[(size_t)(i - 1) * N + k]) < (lp_prop - lp_cur)) x[k] = prop;
+            }
         }
         for (int d = 0; d < D; d++) {
             for (int k = 0; k < N; k++) tmp[k] = x[(size_t)d * N + k] * w[k];

@@ -21,7 +21,7 @@ ERROR_STRINGS = {
     ERR_LENGTH: "Number of particles must match the length of weights",  # R/resampling.R:17
 }
 MODEL = {"lg": 0, "ar1sin": 1, "sir": 2}
-ALGORITHM = {"BPF": 0, "APF": 1}
+ALGORITHM = {"BPF": 0, "APF": 1, "RMPF": 2}
 RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
 RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2}
 TRANSFORM = {"identity": 0, "log": 1, "logit": 2}
@@ -51,6 +51,7 @@ class _PfArgs(C.Structure):
         ("particles_hist", C.c_void_p),
         ("n_trans_calls", C.c_void_p), ("n_res_calls", C.c_void_p),
         ("early_return_step", C.c_void_p), ("resampled", C.c_void_p),
+        ("move_sd", C.c_double), ("z_move", C.c_void_p), ("u_move", C.c_void_p),
     ]
 
 
@@ -131,7 +132,8 @@ def noise_shape(algorithm, T, obs_times=None):
 
 def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
            resample_algorithm="SISAR", resample_fn="stratified", threshold=None,
-           obs_times=None, return_ancestors=False, return_particles=False, seed=0, stream=0):
+           obs_times=None, return_ancestors=False, return_particles=False, seed=0, stream=0,
+           move_sd=0.0, z_move=None, u_move=None):
     """Restatement of .particle_filter_core (R/particle_filter_core.R:19-267)
     with injected random draws.  Returns a dict shaped like the reference's
     result list (state_est, ess, loglike, loglike_history, algorithm[,
@@ -164,7 +166,8 @@ def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
                 -1.0 if threshold is None else float(threshold),
                 _p(theta), _p(y), _p(ot), _p(z_init), _p(z_trans), _p(u_res), int(seed), int(stream),
                 _p(state_est), _p(ess), _p(llh), _p(ll), _p(anc), _p(wh), _p(ph),
-                _p(nt), _p(nr), _p(ers), _p(resampled))
+                _p(nt), _p(nr), _p(ers), _p(resampled), float(move_sd),
+                _p(_d(z_move)) if z_move is not None else None, _p(_d(u_move)) if u_move is not None else None)
     st = lib().orc_pf_run(C.byref(a))
     if st:
         raise ResampleError(st)
@@ -173,7 +176,7 @@ def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
            "n_trans_calls": int(nt[0]), "n_res_calls": int(nr[0]),
            "early_return_step": int(ers[0]), "resampled": resampled[:T]}
     if ers[0] == 0:
-        res["resample_algorithm"] = resample_algorithm   # absent on early return (:192-196)
+        res["resample_algorithm"] = "SISR" if algorithm == "RMPF" else resample_algorithm   # absent on early return (:192-196)
     if return_ancestors:
         res["ancestors"] = anc[: int(nr[0])]
     if return_particles:

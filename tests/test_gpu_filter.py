@@ -314,3 +314,39 @@ def test_threshold_argument(B, ctx, oracle):
         ref = oracle.pf_run("lg", (0.8, 1.0, 1.0), ys, N, d["z_init"], d["z_trans"], d["u_res"],
                             resample_fn="systematic", threshold=thr)
         _compare(res, ref, N)
+
+
+@pytest.mark.parametrize("rf", ["stratified", "systematic"])
+def test_rmpf_injected_draws(B, ctx, oracle, rf):
+    """resample_move_filter (R/resample_move_filter.R:190-236, core :220-234) with the built-in random-walk move."""
+    rng = np.random.default_rng(13)
+    T, N = 20, 2000
+    ys = _simulate(rng, T, 0.8, 1.0, 0.3)
+    d = _draws(rng, oracle, "BPF", T, N, rf)
+    d["z_move"], d["u_move"] = rng.standard_normal((T, N)), rng.random((T, N))
+    m = B.models.linear_gaussian()
+    res = B.resample_move_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, m.rw_move_fn(0.1),
+                                 resample_fn=rf, draws=d, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=0.3)
+    ref = oracle.pf_run("lg", (0.8, 1.0, 0.3), ys, N, d["z_init"], d["z_trans"], d["u_res"], algorithm="RMPF",
+                        resample_fn=rf, move_sd=0.1, z_move=d["z_move"], u_move=d["u_move"], return_particles=True)
+    _compare(res, ref, N)
+    assert res["algorithm"] == "RMPF" and res["resample_algorithm"] == "SISR" and (res["ess"][1:] == N).all()
+    np.testing.assert_allclose(res["particles_history"], ref["particles_history"], rtol=1e-9, atol=1e-12)
+
+
+def test_rmpf_beats_bpf_under_degeneracy(B, ctx):
+    """tests/testthat/test-resample_move_filter.R:1-62 in spirit: informative observations, few particles."""
+    rng = np.random.default_rng(1405)
+    T, N = 50, 20
+    x, xs, ys = rng.standard_normal(), [], []
+    for _ in range(T):
+        x = 0.8 * x + rng.standard_normal()
+        xs.append(x); ys.append(x + 0.05 * rng.standard_normal())
+    m = B.models.linear_gaussian()
+    kw = dict(phi=0.8, sigma_x=1.0, sigma_y=0.05, ctx=ctx, return_particles=False)
+    mse_b, mse_r = [], []
+    for s in range(20):
+        b1 = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, seed=s, **kw)
+        r1 = B.resample_move_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, m.rw_move_fn(0.1), seed=s, **kw)
+        mse_b.append(np.mean((b1["state_est"][1:] - np.array(xs)) ** 2)); mse_r.append(np.mean((r1["state_est"][1:] - np.array(xs)) ** 2))
+    assert np.mean(mse_r) < np.mean(mse_b)
