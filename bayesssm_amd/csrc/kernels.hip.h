@@ -557,6 +557,57 @@ __device__ __forceinline__ uint64_t stepfn_apply(const StepFn& f, uint64_t s, bo
     return (f.mode == 1) ? f.K0 : out;
 }
 
+// A boundary step as plain data in LDS.  The serial part of a scan is a chain of these; run lane-to-lane through
+// v_readlane it cost ~600 cycles a link (scalar branches, VALU->SALU hazards).  walk_chain() instead has every lane of one
+// wave evaluate the SAME dependent sequence from LDS-broadcast constants (next link prefetched), with no data-dependent
+// branch: ~10 dependent VALU ops a link.  Links that are not "simple" (HARD, side entries, window misses) stop the chain;
+// the caller continues from there with the general loop.
+struct alignas(16) WalkFn { uint64_t K0, K1, K2, K3; uint64_t nref, range; int sh; int pad0, pad1, pad2; };   // 64 B
+// a link accepts state s  <=>  (s + nref) <u range      (nref = -(sref + wlo), range = whi - wlo + 1; range 0 = never)
+
+__device__ __forceinline__ WalkFn walkfn_from(const StepFn& f, bool simple)
+{
+    WalkFn w; w.K0 = f.K0; w.K1 = f.K1; w.K2 = f.K2; w.K3 = f.K3; w.sh = f.sh; w.pad0 = w.pad1 = w.pad2 = 0;
+    const bool okwin = simple && f.mode == 0 && f.whi >= f.wlo;
+    w.nref = okwin ? (0ull - (f.sref + (uint64_t)f.wlo)) : 0ull;
+    w.range = okwin ? (uint64_t)(f.whi - f.wlo) + 1ull : 0ull;
+    if (simple && f.mode == 1) {   // ABS: out = K whatever comes in.  States are bit patterns of non-negative doubles (< 2^63), so >> 63 clears them.
+        w.sh = 63; w.nref = 0; w.range = ~0ull;
+    }
+    return w;
+}
+
+__device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// Steps the leading acceptable links of wf[0..nent) from state s (wf needs nent + 1 slots).  Returns how many were stepped
+// (jd) and leaves the state sequence in sseq[0..jd] (sseq[j] = state before link j; s = sseq[jd]).
+__device__ __forceinline__ int walk_chain(const WalkFn* wf, uint64_t* sseq, int nent, uint64_t& s)
+{
+    const uint4* p = reinterpret_cast<const uint4*>(wf);
+    uint4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+    int jbad = nent;
+    uint64_t sv = s;
+#pragma unroll 1
+    for (int j = 0; j < nent; j++) {      // NOT unrolled: this runs once per launch on a cold instruction cache; a compact body is fetched once
+        const uint4 b0 = p[4 * j + 4], b1 = p[4 * j + 5], b2 = p[4 * j + 6], b3 = p[4 * j + 7];     // next link
+        sseq[j] = sv;
+        const uint64_t K0 = mk64(a0.x, a0.y), K1 = mk64(a0.z, a0.w), K2 = mk64(a1.x, a1.y), K3 = mk64(a1.z, a1.w);
+        const bool bad = (sv + mk64(a2.x, a2.y)) >= mk64(a2.z, a2.w);
+        jbad = (bad && j < jbad) ? j : jbad;
+        const uint32_t lo = (uint32_t)sv;
+        const bool bit0 = (lo & 1u) != 0, bit1 = (lo & 2u) != 0;
+        const uint64_t k01 = bit0 ? K1 : K0, k23 = bit0 ? K3 : K2;
+        sv = ((sv & ~3ull) >> (a3.x & 63)) + (bit1 ? k23 : k01);
+        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+    }
+    const int jd = __builtin_amdgcn_readfirstlane(jbad);
+    if (jd == nent) sseq[nent] = sv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    s = sseq[jd];
+    return jd;
+}
+
 __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off)
 {
     int lo = (int)(uint32_t)(uint64_t)v, hi = (int)(uint32_t)((uint64_t)v >> 32);
@@ -568,6 +619,8 @@ struct SegSmem {
     Pure wagg[16]; int wflag[16]; int wnb[16]; Pure wcarry[17]; int wsegbase[17];
     Pure bnd_excl[MAXBND]; Rec bnd_rec[MAXBND]; int bnd_lane[MAXBND]; uint64_t bnd_ent[MAXBND];
     double bnd_terms[MAXBND][EL];    // the terms of every boundary lane (so a literal re-run never chases global memory)
+    WalkFn wf[MAXBND + 1];           // the boundary chain as data (walk_chain)
+    uint64_t sseq[MAXBND + 1];       // its state sequence
     uint64_t seg_start[MAXBND + 1];
     uint64_t lane_exit[4];       // exit state of the last lane of each wave (only [3] is used)
     long long red_min[4][2], red_max[4][2];
@@ -757,23 +810,26 @@ __device__ __forceinline__ bool block_resolve(SegSmem& sm, const BlockScan& bs, 
         Pure ex; ex.d0 = 0; ex.d1 = 0;
         if (lane < nb) { rec = sm.bnd_rec[lane]; ex = sm.bnd_excl[lane]; }
         const StepFn fn = stepfn_build(ex, rec);             // "PURE run + this boundary" folded into constants
-        uint64_t s = cin, my_ent = 0, my_out = 0;
-        for (int j = 0; j < nb; j++) {
+        uint64_t s = cin, my_s = 0, my_out = 0;
+        if (lane < nb) sm.wf[lane] = walkfn_from(fn, true);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int j0 = walk_chain(sm.wf, sm.sseq, nb, s);
+        if (lane < j0) { my_s = sm.sseq[lane]; my_out = sm.sseq[lane + 1]; }
+        for (int j = j0; j < nb; j++) {                      // what the chain could not take (HARD leaves, window misses)
             bool ok;
             uint64_t o = stepfn_apply(fn, s, ok);
-            if (lane == j) {
-                my_ent = pure_step(ex, s);
-                if (!ok) {                                   // HARD leaf / window miss: its 8 terms literally, from LDS
-                    double c = b2d(my_ent);
+            if (!__builtin_amdgcn_readlane((int)ok, j)) {    // boundary j's 8 terms literally, from LDS
+                double c = b2d(pure_step(ex, s));
 #pragma unroll
-                    for (int q = 0; q < EL; q++) c = c + sm.bnd_terms[j][q];
-                    o = d2b(c);
-                }
-                my_out = o;
+                for (int q = 0; q < EL; q++) c = c + sm.bnd_terms[j][q];
+                o = d2b(c);                                  // (every lane computes from the shared terms; only lane j's ex is right)
             }
+            if (lane == j) { my_s = s; my_out = o; }
             const int olo = __builtin_amdgcn_readlane((int)(uint32_t)o, j), ohi = __builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), j);
             s = ((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo;
         }
+        const uint64_t my_ent = pure_step(ex, my_s);
         if (lane == 0) sm.seg_start[0] = cin;
         if (lane < nb) { sm.bnd_ent[lane] = my_ent; sm.seg_start[lane + 1] = my_out; }
     }
@@ -940,12 +996,19 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
 #pragma unroll
         for (int k = 0; k < MAXB / NT; k++) ts0 += es[t * (MAXB / NT) + k];
         double pre = block_excl_scan(ts0, sm.sh4);
+        if (t == (int)blockIdx.x / (MAXB / NT)) {           // the one lane whose slice holds this block: one division
+            double pp = pre;
+            for (int k = 0; k < (int)blockIdx.x % (MAXB / NT); k++) pp += es[t * (MAXB / NT) + k];
+            sm.bcast = pp / S;
+        }
+        if (blockIdx.x == gridDim.x / 2) {                   // one (ordinary) block also publishes every block's prefix, for ain_p later;
+                                                             // not block 0: that one already walks the exact-zero head
 #pragma unroll
-        for (int k = 0; k < MAXB / NT; k++) {
-            const int i = t * (MAXB / NT) + k;
-            if (i == (int)blockIdx.x) sm.bcast = pre / S;
-            if (blockIdx.x == 0 && i < f.nb) f.ain_out[i] = pre / S;
-            pre += es[i];
+            for (int k = 0; k < MAXB / NT; k++) {
+                const int i = t * (MAXB / NT) + k;
+                if (i < f.nb) f.ain_out[i] = pre / S;
+                pre += es[i];
+            }
         }
         __syncthreads();
         a_in = sm.bcast;
@@ -1144,6 +1207,8 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     __shared__ SegSmem sm;
     __shared__ uint64_t final_state;
     __shared__ __attribute__((aligned(16))) SideEntry sideC[64];
+    __shared__ WalkFn wfr[65];
+    __shared__ uint64_t sseq[65];
     const int t = threadIdx.x;
     // run-state words are fetched together with the block records (checked after the staging barrier)
     const int s_dead = st->dead, s_do = st->do_resample, dbg0 = st->debug_stop;
@@ -1229,8 +1294,17 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
             uint64_t s = 0, my_in = 0, my_out = 0;
             const bool special = (bidx >= 0) && (slow || nside == 1);
             const StepFn fn = stepfn_build(ex, pr);          // "PURE run + this block's record" folded into constants
+            if (lane < nent) wfr[lane] = walkfn_from(fn, bidx >= 0 && !special);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             BSSM_STAMP(st, dbg0, MODE, 10, t == 0 && fn.mode >= 0);
-            for (int j = 0; j < nent; j++) {
+            // (MODE_P: nobody needs the state after the last block -- skip its link, usually the slow one)
+            const int blast = __builtin_amdgcn_readlane(bidx, nent - 1);
+            const int nstep = (MODE == MODE_P && blast == B - 1) ? nent - 1 : nent;
+            const int j0 = walk_chain(wfr, sseq, nstep, s);
+            if (lane < j0) { my_in = pure_step(ex, sseq[lane]); my_out = sseq[lane + 1]; }
+            if (dbg0 == 99 && t == 0) { st->stamps[MODE][12] = j0; st->stamps[MODE][13] = clock64(); }
+            for (int j = j0; j < nstep; j++) {
                 bool ok;
                 uint64_t o = stepfn_apply(fn, s, ok);
                 const uint64_t e = pure_step(ex, s);         // (only lane j's copy is used)
@@ -1262,6 +1336,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
                 const int olo = __builtin_amdgcn_readlane((int)(uint32_t)o, j), ohi = __builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), j);
                 s = ((uint64_t)(uint32_t)ohi << 32) | (uint32_t)olo;
             }
+            if (nstep < nent && lane == nent - 1) { my_in = pure_step(ex, s); my_out = 0; }
             BSSM_STAMP(st, dbg0, MODE, 11, t == 0 && s != 1);
             if (lane == 0) sm.seg_start[0] = 0;
             if (have) {

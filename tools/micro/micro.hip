@@ -34,6 +34,54 @@ __global__ void k(long long* out, const double* g, double* sink, int reps)
     sink[t] = x;
 }
 
+
+// dependent-op latencies and the boundary chain, one wave
+__global__ void k2(long long* out, const uint64_t* g, uint64_t* sink, int reps)
+{
+    __shared__ WalkFn wf[65];
+    __shared__ uint64_t sseq[65];
+    const int t = threadIdx.x;
+    if (t >= 64) return;
+    uint64_t x = g[t] + 12345;
+    uint32_t y = (uint32_t)g[t] + 77;
+    long long c0, c1; int slot = 0;
+#define M2(body, div) { c0 = clock64(); for (int r = 0; r < reps; r++) { body; } c1 = clock64(); if (t == 0) out[slot] = (c1 - c0) * 10 / (reps * (div)); slot++; }
+    M2(_Pragma("unroll") for (int q = 0; q < 32; q++) y = y * 3u + 1u;, 32)                       // 0 mad u32
+    M2(_Pragma("unroll") for (int q = 0; q < 32; q++) y = (y ^ (y >> 3)) + 5u;, 32)               // 1 shift,xor,add u32 (3 ops)
+    M2(_Pragma("unroll") for (int q = 0; q < 32; q++) x = x + (x >> 7);, 32)                       // 2 shift64 + add64
+    M2(_Pragma("unroll") for (int q = 0; q < 32; q++) x = x + 0x123456789ull;, 32)                 // 3 add64
+    M2(_Pragma("unroll") for (int q = 0; q < 32; q++) x = (x & 1) ? x + 3 : x + 0x55;, 32)         // 4 and,cmp,cndmask x2, add64
+    M2(_Pragma("unroll") for (int q = 0; q < 32; q++) y = (y & 1) ? y + 3 : y + 0x55;, 32)         // 5 same in u32
+    { StepFn f; f.K0 = 4; f.K1 = 9; f.K2 = 14; f.K3 = 19; f.sref = 0; f.wlo = -(1ll << 60); f.whi = 1ll << 60; f.sh = 0; f.mode = 0;
+      for (int j = t; j < 65; j += 64) wf[j] = walkfn_from(f, true);
+      __builtin_amdgcn_wave_barrier();
+      uint64_t s = x & 0xffff;
+      M2(walk_chain(wf, sseq, 16, s), 16)                                                          // 6 walk_chain per link
+      x += s; }
+    sink[t] = x + y;
+}
+
+
+// the boundary chain executed ONCE in a freshly launched kernel (cold instruction cache), as the resolver does
+__global__ void k3(long long* out, const uint64_t* g, uint64_t* sink, int nlinks)
+{
+    __shared__ WalkFn wf[65];
+    __shared__ uint64_t sseq[65];
+    const int t = threadIdx.x;
+    if (t >= 64) return;
+    StepFn f; f.K0 = 4; f.K1 = 9; f.K2 = 14; f.K3 = 19; f.sref = 0; f.wlo = -(1ll << 60); f.whi = 1ll << 60; f.sh = 0; f.mode = 0;
+    for (int j = t; j < 65; j += 64) wf[j] = walkfn_from(f, true);
+    __builtin_amdgcn_wave_barrier();
+    uint64_t s = g[t] & 0xffff;
+    long long c0 = clock64();
+    walk_chain(wf, sseq, nlinks, s);
+    long long c1 = clock64();
+    walk_chain(wf, sseq, nlinks, s);
+    long long c2 = clock64();
+    if (t == 0) { out[0] = c1 - c0; out[1] = c2 - c1; }
+    sink[t] = s;
+}
+
 int main()
 {
     long long* out; double *g, *sink;
@@ -45,5 +93,16 @@ int main()
     const char* names[] = {"barrier", "wave DPP incl scan f64", "block_excl_scan", "LDS wr+bar+rd+bar", "exp", "div", "log",
                            "dependent global load", "block_sum", "seg_excl_scan<4>", "chunk_record<8>", "philox+box-muller pair"};
     for (int i = 0; i < 12; i++) printf("%-28s %6lld cycles\n", names[i], h[i]);
+    hipMemset(out, 0, 64 * 8);
+    for (int it = 0; it < 2; it++) hipLaunchKernelGGL(k2, dim3(1), dim3(256), 0, 0, out, (const uint64_t*)g, (uint64_t*)sink, 20);
+    hipDeviceSynchronize();
+    hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost);
+    const char* n2[] = {"u32 mad (dep)", "u32 shift+xor+add (3 dep ops)", "u64 shift+add", "u64 add", "u64 and/cmp/cndmask/add", "u32 and/cmp/cndmask/add", "walk_chain per link"};
+    for (int i = 0; i < 7; i++) printf("%-34s %6.1f cycles\n", n2[i], h[i] / 10.0);
+    hipMemset(out, 0, 64 * 8);
+    hipLaunchKernelGGL(k3, dim3(1), dim3(256), 0, 0, out, (const uint64_t*)g, (uint64_t*)sink, 10);
+    hipDeviceSynchronize();
+    hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost);
+    printf("walk_chain, 10 links, first execution in a fresh kernel: %lld cycles; second execution: %lld cycles\n", h[0], h[1]);
     return 0;
 }
