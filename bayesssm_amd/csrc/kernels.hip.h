@@ -291,11 +291,10 @@ struct NoiseSrc {
 // k_init: init_fn = rnorm(N, 0, 1)   (R/particle_filter_core.R:76), t = 0 state
 // estimate partial sums (:109)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_init(double* __restrict__ x, long long N, NoiseSrc ns,
-                                             double* __restrict__ se_part /* [nblocks][dim] */, int model, ModelPar par)
+__device__ __forceinline__ void init_block(double* sh4, const int bidx, double* __restrict__ x, long long N, const NoiseSrc& ns,
+                                           double* __restrict__ se_part /* [nblocks][dim] */, int model, const ModelPar& par)
 {
-    __shared__ double sh4[4];
-    const long long base = (long long)blockIdx.x * EB;
+    const long long base = (long long)bidx * EB;
     const double invN = 1.0 / (double)N;
     double acc = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -318,7 +317,14 @@ __global__ __launch_bounds__(NT) void k_init(double* __restrict__ x, long long N
     const int dim = (model == 2) ? 2 : 1;
     acc = block_sum(acc, sh4);
     if (dim > 1) acc1 = block_sum(acc1, sh4);
-    if (threadIdx.x == 0) { se_part[(long long)blockIdx.x * dim] = acc; if (dim > 1) se_part[(long long)blockIdx.x * dim + 1] = acc1; }
+    if (threadIdx.x == 0) { se_part[(long long)bidx * dim] = acc; if (dim > 1) se_part[(long long)bidx * dim + 1] = acc1; }
+}
+
+__global__ __launch_bounds__(NT) void k_init(double* __restrict__ x, long long N, NoiseSrc ns,
+                                             double* __restrict__ se_part /* [nblocks][dim] */, int model, ModelPar par)
+{
+    __shared__ double sh4[4];
+    init_block(sh4, (int)blockIdx.x, x, N, ns, se_part, model, par);
 }
 
 // ---------------------------------------------------------------------------
@@ -912,32 +918,32 @@ struct FromLw {
     double* ess_out; double* llh_out; int* resampled_out;
 };
 
-template <int MODE, bool FROM_LW>
-__global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long long nw, const double* __restrict__ ain,
-                                              int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
-                                              FromLw f)
+// The body of k_local for workgroup `bidx` of `nblk`; shared storage is handed in so that the batched small-filter kernel
+// (k_pf_batch: one workgroup runs a whole filter, nblk == 1) executes exactly this code.  MAXBL: capacity of the partials.
+template <int MODE, bool FROM_LW, int MAXBL>
+__device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin, double* es /* [MAXBL], FROM_LW only */, const int bidx, const int nblk,
+                                            const double* __restrict__ w, long long nw, const double* __restrict__ ain,
+                                            int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
+                                            const FromLw& f)
 {
-    __shared__ SegSmem sm;
-    __shared__ uint64_t tin[NT];
     const int t = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * EB;
+    const long long b0 = (long long)bidx * EB;
     // run-state words and this lane's terms are fetched together (one memory round trip, not two)
     const int s_dead = st->dead, s_do = st->do_resample, dbg = st->debug_stop;
     const uint32_t s_flags = st->flags;
     const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
     double vraw[EL];
     if (!FROM_LW) load_terms<MODE_W>(w, nw, 1.0, b0 + (long long)t * EL, vraw);
-    const double a_in_pre = FROM_LW ? 0.0 : ain[blockIdx.x];
+    const double a_in_pre = FROM_LW ? 0.0 : ain[bidx];
     if (s_dead || s_flags) return;
     if (!FROM_LW && !s_do) return;
-    const bool stamper = (t == 0 && blockIdx.x == (gridDim.x > 100 ? 100u : 0u));
+    const bool stamper = (t == 0 && bidx == (nblk > 100 ? 100 : 0));
     BSSM_STAMP(st, dbg, 2, FROM_LW ? 4 : 0, stamper);
     double v[EL];
     double a_in;
     if (FROM_LW) {
         // global (max, sum exp) from the per-block partials, and -- from the same numbers -- the approximate
         // exclusive block prefixes of w:  sum_b w = ps[b] exp(pm[b] - M) / S
-        __shared__ double es[MAXB];
         // issue this thread's log-weight loads first: their latency hides under the reductions below
         const long long j0 = b0 + (long long)t * EL;
         double l8[EL];
@@ -950,27 +956,27 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
             for (int k = 0; k < EL; k++) l8[k] = (j0 + k < nw) ? f.lw[j0 + k] : -INFINITY;
         }
         // all three partial arrays are fetched up front (one memory round trip), then reduced
-        double pmv[MAXB / NT], psv[MAXB / NT], pqv[MAXB / NT];
+        double pmv[MAXBL / NT], psv[MAXBL / NT], pqv[MAXBL / NT];
 #pragma unroll
-        for (int k = 0; k < MAXB / NT; k++) {
+        for (int k = 0; k < MAXBL / NT; k++) {
             const int i = t + NT * k;
             const bool in = i < f.nb;
             pmv[k] = in ? f.pm[i] : -INFINITY; psv[k] = in ? f.ps[i] : 0.0; pqv[k] = in ? f.pq[i] : 0.0;
         }
         double m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < MAXB / NT; k++) m = fmax(m, pmv[k]);
+        for (int k = 0; k < MAXBL / NT; k++) m = fmax(m, pmv[k]);
         const double M = block_max(m, sm.sh4);
         const bool degenerate = (f.plan == PLAN_PF) && (M < -1e8);       // all(log_weights < -1e8)  (:189-202)
         if (degenerate) {
-            if (blockIdx.x == 0 && t == 0) {
+            if (bidx == 0 && t == 0) {
                 st->loglike = -INFINITY; f.llh_out[f.obs_i - 1] = -INFINITY; st->dead = f.obs_i; st->do_resample = 0;
             }
             return;
         }
         double se = 0.0, sq = 0.0;
 #pragma unroll
-        for (int k = 0; k < MAXB / NT; k++) {
+        for (int k = 0; k < MAXBL / NT; k++) {
             const int i = t + NT * k;
             double x = 0.0;
             if (pmv[k] > -INFINITY) { const double ex = exp(pmv[k] - M); x = psv[k] * ex; sq += pqv[k] * ex * ex; }
@@ -982,7 +988,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
         if (f.plan == PLAN_PF) {
             const double ess = 1.0 / (sq / (S * S));                                          // :211
             doit = (f.resample_algorithm == 0) ? 0 : (f.resample_algorithm == 1) ? 1 : (ess < f.threshold);   // :214-218
-            if (blockIdx.x == 0 && t == 0) {
+            if (bidx == 0 && t == 0) {
                 const double ll = st->loglike + (M + log(S) - log((double)f.N));              // :208
                 st->loglike = ll; f.llh_out[f.obs_i - 1] = ll;                                // :209
                 st->do_resample = doit;
@@ -991,21 +997,21 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
                 st->ess = ess; st->lse_max = M; st->lse_sum = S;
                 if (doit) { st->cur_call = st->res_calls; st->res_calls += 1; }
             }
-        } else if (blockIdx.x == 0 && t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
+        } else if (bidx == 0 && t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
         double ts0 = 0.0;
 #pragma unroll
-        for (int k = 0; k < MAXB / NT; k++) ts0 += es[t * (MAXB / NT) + k];
+        for (int k = 0; k < MAXBL / NT; k++) ts0 += es[t * (MAXBL / NT) + k];
         double pre = block_excl_scan(ts0, sm.sh4);
-        if (t == (int)blockIdx.x / (MAXB / NT)) {           // the one lane whose slice holds this block: one division
+        if (t == bidx / (MAXBL / NT)) {           // the one lane whose slice holds this block: one division
             double pp = pre;
-            for (int k = 0; k < (int)blockIdx.x % (MAXB / NT); k++) pp += es[t * (MAXB / NT) + k];
+            for (int k = 0; k < bidx % (MAXBL / NT); k++) pp += es[t * (MAXBL / NT) + k];
             sm.bcast = pp / S;
         }
-        if (blockIdx.x == gridDim.x / 2) {                   // one (ordinary) block also publishes every block's prefix, for ain_p later;
+        if (bidx == nblk / 2) {                   // one (ordinary) block also publishes every block's prefix, for ain_p later;
                                                              // not block 0: that one already walks the exact-zero head
 #pragma unroll
-            for (int k = 0; k < MAXB / NT; k++) {
-                const int i = t * (MAXB / NT) + k;
+            for (int k = 0; k < MAXBL / NT; k++) {
+                const int i = t * (MAXBL / NT) + k;
                 if (i < f.nb) f.ain_out[i] = pre / S;
                 pre += es[i];
             }
@@ -1055,7 +1061,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
 #pragma unroll
             for (int k = 0; k < EL; k++) c = c + v[k];
             BlockRec br; br.prefix = rec_abs(d2b(c)); br.tail_from = NT; br.nside = 0;
-            brec[blockIdx.x] = br;
+            brec[bidx] = br;
         }
         return;
     }
@@ -1081,7 +1087,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
     if (bs.nb == 0) {
         if (t == NT - 1) {
             BlockRec br; br.prefix = pure_to_rec(bs.last_seg, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
-            br.tail_from = NT; br.nside = 0; brec[blockIdx.x] = br;
+            br.tail_from = NT; br.nside = 0; brec[bidx] = br;
         }
         return;
     }
@@ -1096,13 +1102,13 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
                 const Rec post = pure_to_rec(bs.last_seg, sm.seg1_base, -(long long)lim - mn[1] + 4, (long long)lim - mx[1] - 4);
                 r = rec_compose(r, post);
             }
-            if (r.kind != REC_HARD) { br.prefix = r; br.tail_from = NT; br.nside = 0; brec[blockIdx.x] = br; done1 = true; }
+            if (r.kind != REC_HARD) { br.prefix = r; br.tail_from = NT; br.nside = 0; brec[bidx] = br; done1 = true; }
         }
         if (!done1) {
             br.prefix = pre;
             if (bs.nb <= MAXBND) { br.tail_from = NT; br.nside = bs.nb; }     // side list below
             else { br.tail_from = fb; br.nside = 0; }                          // too many: literal tail
-            brec[blockIdx.x] = br;
+            brec[bidx] = br;
             atomicAdd((unsigned long long*)&st->stat_hard_blocks, 1ull);
         }
         sm.fail = done1 ? 1 : 0;      // reuse as "record complete" flag for the block
@@ -1127,7 +1133,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
     __syncthreads();
     if (bs.isb) {
         const int k = bs.seg;
-        SideEntry& e = side[blockIdx.x].e[k];
+        SideEntry& e = side[bidx].e[k];
         e.leaf = bs.leaf;
         const Pure post = (k + 1 < bs.nb) ? sm.bnd_excl[k + 1] : bs.last_seg;
         e.d0 = post.d0; e.d1 = post.d1;
@@ -1141,6 +1147,18 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
 #pragma unroll
         for (int q = 0; q < EL; q++) e.terms[q] = v[q];     // so the resolver can re-run this leaf without chasing w[]
     }
+}
+
+
+template <int MODE, bool FROM_LW>
+__global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long long nw, const double* __restrict__ ain,
+                                              int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
+                                              FromLw f)
+{
+    __shared__ SegSmem sm;
+    __shared__ uint64_t tin[NT];
+    __shared__ double es[FROM_LW ? MAXB : 1];
+    local_block<MODE, FROM_LW, MAXB>(sm, tin, es, (int)blockIdx.x, (int)gridDim.x, w, nw, ain, lim, brec, side, st, f);
 }
 
 // ---------------------------------------------------------------------------
@@ -1414,14 +1432,11 @@ struct ApplyArgs {
 };
 
 template <int KIND>
-__global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
+__device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
+                                            const ApplyArgs& a, DevState* st)
 {
-    __shared__ SegSmem sm;
-    __shared__ uint64_t tin[NT];
-    __shared__ int Tl[EB];
-    __shared__ int Tbegin;
     const int t = threadIdx.x;
-    const long long b0 = (long long)blockIdx.x * EB;
+    const long long b0 = (long long)bidx * EB;
     // run-state words and this lane's terms are fetched together (one memory round trip, not two)
     const int s_dead = st->dead, s_do = st->do_resample, call = st->cur_call, dbg = st->debug_stop;
     const uint32_t s_flags = st->flags;
@@ -1443,15 +1458,15 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
         }
         if (a.auxdst) load_terms<MODE_W>(a.auxsrc, a.nw, 1.0, b0 + (long long)t * EL, axs);
     }
-    const double a_in_p = a.ain_p[blockIdx.x];
-    const uint64_t cinb = a.cin[blockIdx.x];
+    const double a_in_p = a.ain_p[bidx];
+    const uint64_t cinb = a.cin[bidx];
     if (s_dead || !s_do || s_flags) return;
     // the uniform(s) of this resample call (systematic: one draw; computed here, under the load latency)
     UniformSrc us;
     us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
     us.key = a.key; us.call = (uint32_t)call;
     const double Usys = (KIND == 1) ? us(0) : 0.0;
-    const bool stamper = (t == 0 && blockIdx.x == (gridDim.x > 100 ? 100u : 0u));
+    const bool stamper = (t == 0 && bidx == (nblk > 100 ? 100 : 0));
     BSSM_STAMP(st, dbg, 3, 0, stamper);
 #pragma unroll
     for (int k = 0; k < EL; k++) v[k] = v[k] / total;                  // prob = weights / total (src/resampling.cpp:24,51)
@@ -1484,7 +1499,7 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     BSSM_STAMP(st, dbg, 3, 4, stamper);
     if (t == 0) {
         int tb = 0;
-        if (blockIdx.x > 0) {
+        if (bidx > 0) {
             const double cprev = b2d(cinb);
             tb = (KIND == 1) ? count_le_systematic(cprev, a.n, Usys) : count_le_stratified(cprev, a.n, us);
         }
@@ -1545,9 +1560,20 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     if (a.se_part) {
         acc0 = block_sum(acc0, sm.sh4);
         if (a.dim > 1) acc1 = block_sum(acc1, sm.sh4);
-        if (t == 0) { a.se_part[(long long)blockIdx.x * a.dim] = acc0; if (a.dim > 1) a.se_part[(long long)blockIdx.x * a.dim + 1] = acc1; }
+        if (t == 0) { a.se_part[(long long)bidx * a.dim] = acc0; if (a.dim > 1) a.se_part[(long long)bidx * a.dim + 1] = acc1; }
     }
     BSSM_STAMP(st, dbg, 3, 6, stamper);
+}
+
+
+template <int KIND>
+__global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
+{
+    __shared__ SegSmem sm;
+    __shared__ uint64_t tin[NT];
+    __shared__ int Tl[EB];
+    __shared__ int Tbegin;
+    apply_block<KIND>(sm, tin, Tl, Tbegin, (int)blockIdx.x, (int)gridDim.x, a, st);
 }
 
 // multinomial: inverse CDF on the exact cum_sum (distributional parity only)
@@ -1633,13 +1659,12 @@ __global__ void k_dump_move(PhiloxKey key, uint32_t call, long long n, double* _
 
 // no resampling at this observation: particles carry over; state estimate is
 // sum(particles * weights) with the normalised weights (:238)
-__global__ __launch_bounds__(NT) void k_carry(const double* __restrict__ xsrc, double* __restrict__ xdst,
-                                              const double* __restrict__ w, long long N, int dim,
-                                              double* __restrict__ se_part, const DevState* __restrict__ st)
+__device__ __forceinline__ void carry_block(double* sh4, const int bidx, const double* __restrict__ xsrc, double* __restrict__ xdst,
+                                            const double* __restrict__ w, long long N, int dim,
+                                            double* __restrict__ se_part, const DevState* __restrict__ st)
 {
     if (st->dead || st->do_resample) return;
-    __shared__ double sh4[4];
-    const long long base = (long long)blockIdx.x * EB;
+    const long long base = (long long)bidx * EB;
     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
     for (int r = 0; r < EL; r++) {
@@ -1653,7 +1678,15 @@ __global__ __launch_bounds__(NT) void k_carry(const double* __restrict__ xsrc, d
     }
     acc0 = block_sum(acc0, sh4);
     if (dim > 1) acc1 = block_sum(acc1, sh4);
-    if (threadIdx.x == 0) { se_part[(long long)blockIdx.x * dim] = acc0; if (dim > 1) se_part[(long long)blockIdx.x * dim + 1] = acc1; }
+    if (threadIdx.x == 0) { se_part[(long long)bidx * dim] = acc0; if (dim > 1) se_part[(long long)bidx * dim + 1] = acc1; }
+}
+
+__global__ __launch_bounds__(NT) void k_carry(const double* __restrict__ xsrc, double* __restrict__ xdst,
+                                              const double* __restrict__ w, long long N, int dim,
+                                              double* __restrict__ se_part, const DevState* __restrict__ st)
+{
+    __shared__ double sh4[4];
+    carry_block(sh4, (int)blockIdx.x, xsrc, xdst, w, N, dim, se_part, st);
 }
 
 // state_est[i] = sum over blocks of the partials written for observation i
