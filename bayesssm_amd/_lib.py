@@ -42,6 +42,11 @@ class PfResult(C.Structure):
         "ancestors", "particles_history", "weights_history", "device_ms", "scan_stats")]
 
 
+class PfBatchResult(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in (
+        "loglike", "state_est", "ess", "loglike_history", "early_return_step", "n_res_calls", "status", "device_ms")]
+
+
 class PmmhConfig(C.Structure):
     _fields_ = [
         ("pf", PfConfig), ("m", C.c_int), ("n_params", C.c_int),
@@ -100,6 +105,8 @@ def load():
     lib.bssm_dump_uniforms.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_longlong, C.c_void_p]
     lib.bssm_dump_move_draws.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
     lib.bssm_pmmh_chain.argtypes = [C.c_void_p, C.POINTER(PmmhConfig), C.POINTER(PmmhResult)]
+    lib.bssm_pf_run_batch.argtypes = [C.c_void_p, C.POINTER(PfConfig), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(PfBatchResult)]
     _lib = lib
     return lib
 
@@ -110,6 +117,7 @@ EXPORTED_SYMBOLS = [
     "bssm_resample_multinomial", "bssm_resample_device", "bssm_resample_device_status", "bssm_resample_ex",
     "bssm_pf_run", "bssm_pf_noise_shape", "bssm_dump_normals", "bssm_dump_uniforms", "bssm_dump_move_draws",
     "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_pmmh_chain",
+    "bssm_pf_run_batch", "bssm_pf_batch_max_particles",
 ]
 
 

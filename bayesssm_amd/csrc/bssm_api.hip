@@ -643,6 +643,105 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     return BSSM_OK;
 }
 
+// ---- many small filters per launch (one workgroup = one whole filter) -------------------------
+extern "C" int bssm_pf_batch_max_particles(void) { return EB; }
+
+extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_filters, const double* thetas,
+                                 const unsigned long long* seeds, const unsigned long long* streams, bssm_pf_batch_result* res)
+{
+    if (!c || !cfg || !res || !thetas || !seeds || !streams) ARGFAIL("bssm_pf_run_batch: NULL argument");
+    const long long N = cfg->num_particles;
+    const int T = cfg->T, F = n_filters;
+    if (F <= 0) ARGFAIL("bssm_pf_run_batch: n_filters must be positive");
+    if (N <= 0) ARGFAIL("num_particles must be a positive count");
+    if (N > EB) { g_err = "bssm_pf_run_batch: a batched filter holds at most 2048 particles (one workgroup); use bssm_pf_run"; return BSSM_ERR_CAPACITY; }
+    if (T < 0) ARGFAIL("bssm_pf_run_batch: T must be >= 0");
+    if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN) ARGFAIL("bssm_pf_run_batch: built-in scalar models only (linear-Gaussian, AR1+sin)");
+    if (cfg->algorithm != BSSM_BPF) ARGFAIL("bssm_pf_run_batch: bootstrap filter only");
+    if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run_batch: unknown resample_algorithm");
+    if (cfg->resample_fn != BSSM_STRATIFIED && cfg->resample_fn != BSSM_SYSTEMATIC) ARGFAIL("bssm_pf_run_batch: stratified or systematic resampling only");
+    if (cfg->z_init || cfg->z_trans || cfg->u_res || cfg->return_particles || cfg->return_ancestors)
+        ARGFAIL("bssm_pf_run_batch: injected draws and histories are not available in the batched path");
+    if (cfg->n_theta < 3) ARGFAIL("bssm_pf_run_batch: theta rows must hold (phi, sigma_x, sigma_y)");
+    if (T > 0 && !cfg->y) ARGFAIL("bssm_pf_run_batch: y is NULL");
+    if (!res->loglike) ARGFAIL("bssm_pf_run_batch: loglike buffer missing");
+    for (int i = 0; i < T; i++) if (!isfinite(cfg->y[i])) ARGFAIL("Assertion on 'y' failed: Contains missing values");
+    if (cfg->obs_times) {
+        int prev = 1;
+        for (int i = 0; i < T; i++) { if (cfg->obs_times[i] < prev) ARGFAIL("Assertion on 'obs_times' failed: Must be sorted and >= 1"); prev = cfg->obs_times[i]; }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const double dN = (double)N;
+    double threshold = cfg->threshold;
+    if (threshold < 0) threshold = (cfg->resample_algorithm == BSSM_SIS) ? INFINITY : (cfg->resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
+    const int nth = cfg->n_theta;
+    void *d_y, *d_ot = nullptr, *d_th, *d_keys, *d_ll, *d_se, *d_ess, *d_llh, *d_dead, *d_flags, *d_res;
+    int rc;
+    const size_t rowsT1 = (size_t)F * (T + 1) * 8, rowsT = (size_t)F * std::max(T, 1) * 8;
+    if ((rc = pool_get(c, "b_y", (size_t)std::max(T, 1) * 8, &d_y))) return rc;
+    if (cfg->obs_times && (rc = pool_get(c, "b_ot", (size_t)std::max(T, 1) * 4, &d_ot))) return rc;
+    if ((rc = pool_get(c, "b_th", (size_t)F * nth * 8, &d_th))) return rc;
+    if ((rc = pool_get(c, "b_keys", (size_t)F * sizeof(PhiloxKey), &d_keys))) return rc;
+    if ((rc = pool_get(c, "b_ll", (size_t)F * 8, &d_ll))) return rc;
+    if ((rc = pool_get(c, "b_se", rowsT1, &d_se))) return rc;
+    if ((rc = pool_get(c, "b_ess", rowsT1, &d_ess))) return rc;
+    if ((rc = pool_get(c, "b_llh", rowsT, &d_llh))) return rc;
+    if ((rc = pool_get(c, "b_dead", (size_t)F * 4, &d_dead))) return rc;
+    if ((rc = pool_get(c, "b_flags", (size_t)F * 4, &d_flags))) return rc;
+    if ((rc = pool_get(c, "b_res", (size_t)F * 4, &d_res))) return rc;
+    std::vector<PhiloxKey> keys((size_t)F);
+    for (int f = 0; f < F; f++) keys[f] = make_key(seeds[f], streams[f]);
+    if (T > 0) HIPCHK(hipMemcpyAsync(d_y, cfg->y, (size_t)T * 8, hipMemcpyHostToDevice, c->stream));
+    if (d_ot && T > 0) HIPCHK(hipMemcpyAsync(d_ot, cfg->obs_times, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_th, thetas, (size_t)F * nth * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_keys, keys.data(), (size_t)F * sizeof(PhiloxKey), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(d_se, 0, rowsT1, c->stream));
+    HIPCHK(hipMemsetAsync(d_ess, 0, rowsT1, c->stream));
+    HIPCHK(hipMemsetAsync(d_llh, 0, rowsT, c->stream));
+    BatchArgs g;
+    g.N = (int)N; g.T = T; g.resample_algorithm = cfg->resample_algorithm; g.resample_fn = cfg->resample_fn;
+    g.lim = g_debug_lim > 0 ? g_debug_lim : rec_window(N);
+    g.threshold = threshold; g.y = (const double*)d_y; g.obs_times = (const int*)d_ot;
+    g.theta = (const double*)d_th; g.theta_stride = nth; g.keys = (const PhiloxKey*)d_keys;
+    g.loglike = (double*)d_ll; g.state_est = (double*)d_se; g.ess = (double*)d_ess; g.llh = (double*)d_llh;
+    g.dead = (int*)d_dead; g.flags = (uint32_t*)d_flags; g.res_calls = (int*)d_res;
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_pf_batch", k_pf_batch<0>, F, NT, 0, g);
+    else LAUNCH(c, "k_pf_batch", k_pf_batch<1>, F, NT, 0, g);
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipGetLastError());
+    std::vector<int> dead((size_t)F), nres((size_t)F);
+    std::vector<uint32_t> flags((size_t)F);
+    HIPCHK(hipMemcpyAsync(res->loglike, d_ll, (size_t)F * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(dead.data(), d_dead, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(flags.data(), d_flags, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(nres.data(), d_res, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
+    if (res->state_est) HIPCHK(hipMemcpyAsync(res->state_est, d_se, rowsT1, hipMemcpyDeviceToHost, c->stream));
+    if (res->ess) HIPCHK(hipMemcpyAsync(res->ess, d_ess, rowsT1, hipMemcpyDeviceToHost, c->stream));
+    if (res->loglike_history && T > 0) HIPCHK(hipMemcpyAsync(res->loglike_history, d_llh, (size_t)F * T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (res->device_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *res->device_ms = ms; }
+    int first_bad = BSSM_OK;
+    for (int f = 0; f < F; f++) {
+        if (res->ess) res->ess[(size_t)f * (T + 1)] = 1.0 / (dN * ((1.0 / dN) * (1.0 / dN)));       // :106-107
+        if (res->early_return_step) res->early_return_step[f] = dead[f];
+        if (res->n_res_calls) res->n_res_calls[f] = nres[f];
+        if (dead[f]) {                                // the reference returns at once: later rows keep their initial values (:90-97)
+            for (int i = dead[f]; i <= T; i++) {
+                if (res->ess) res->ess[(size_t)f * (T + 1) + i] = 0.0;
+                if (res->state_est) res->state_est[(size_t)f * (T + 1) + i] = 0.0;
+            }
+            if (res->loglike_history) for (int i = dead[f]; i < T; i++) res->loglike_history[(size_t)f * T + i] = 0.0;
+        }
+        const int stf = flags[f] ? flags_to_status(flags[f]) : BSSM_OK;
+        if (res->status) res->status[f] = stf;
+        if (stf && !first_bad) first_bad = stf;
+    }
+    if (first_bad && !res->status) { g_err = bssm_status_string(first_bad); return first_bad; }
+    return BSSM_OK;
+}
+
 // ---- PMMH: one chain --------------------------------------------------------------------
 // Chain-level draws (proposal normals, acceptance uniform) come from the same
 // counter-based generator, keyed by the chain seed: results do not depend on

@@ -1732,6 +1732,195 @@ __global__ void k_dump_uniforms(PhiloxKey key, uint32_t call, long long n, doubl
     if (i < n) out[i] = resample_uniform(key, call, (uint32_t)i);
 }
 
+// ---------------------------------------------------------------------------
+// k_pf_batch: many small bootstrap filters per launch (the pilot's 100 filter runs at N = 100, PMMH
+// chains at the reference's native N <= 1000).  ONE workgroup runs ONE whole filter: all T observations inside the
+// kernel, particles / log-weights / weights in LDS, no launches and no HBM traffic inside the loop.
+// The arithmetic is the multi-launch path's, call for call: the same *_block bodies with nblk == 1, and the 1024-thread
+// k_step reductions re-enacted by 256 threads in the same association order -- so a batched filter returns bit-for-bit
+// what bssm_pf_run returns for the same (theta, seed, stream).
+// ---------------------------------------------------------------------------
+struct BatchArgs {
+    int N, T, resample_algorithm, resample_fn, lim;
+    double threshold;
+    const double* y; const int* obs_times;            // [T]; obs_times may be nullptr (1..T)
+    const double* theta; int theta_stride;            // [F][theta_stride]: phi, sigma_x, sigma_y
+    const PhiloxKey* keys;                            // [F]
+    double* loglike; double* state_est; double* ess; double* llh;    // [F], [F][T+1], [F][T+1], [F][T]
+    int* dead; uint32_t* flags; int* res_calls;       // [F]
+};
+
+// k_step<MODEL, TRANS, WEIGHT, false> for one block of up to EB particles, by NT threads: thread t plays the threads
+// t, t + NT, t + 2 NT, t + 3 NT of the NTS-thread kernel (wave w of round r = wave w + 4 r there).
+template <int MODEL, bool TRANS, int WEIGHT>
+__device__ __forceinline__ void step_emul(double* sh16, double* x, double* __restrict__ lw, long long N, const ModelPar& par, double y,
+                                          const NoiseSrc& ns, double* pm, double* ps, double* pq)
+{
+    constexpr int R = NTS / NT;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double l0[R], l1[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const long long j = 2 * (long long)(t + NT * r);
+        l0[r] = -INFINITY; l1[r] = -INFINITY;
+        if (j < N) {
+            const bool two = (j + 1 < N);
+            double x0 = x[j], x1 = two ? x[j + 1] : 0.0;
+            if (TRANS) {
+                double z0, z1;
+                normal_pair(ns.key, ns.purpose, ns.call, 0, (uint32_t)(j >> 1), z0, z1);
+                x0 = Model<MODEL>::transition(x0, z0, par);
+                x1 = Model<MODEL>::transition(x1, z1, par);
+                x[j] = x0; if (two) x[j + 1] = x1;
+            }
+            if (WEIGHT) {
+                l0[r] = r_dnorm_log(y, x0, par.sy, par.log_sy);
+                l1[r] = r_dnorm_log(y, x1, par.sy, par.log_sy);
+                lw[j] = l0[r];
+                if (two) lw[j + 1] = l1[r]; else l1[r] = -INFINITY;
+            }
+        }
+    }
+    if (WEIGHT) {
+        double v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = wave_max(fmax(l0[r], l1[r]));
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) sh16[wave + (NT / 64) * r] = v[r];
+        }
+        __syncthreads();
+        double bm = sh16[0];
+#pragma unroll
+        for (int i = 1; i < NTS / 64; i++) bm = fmax(bm, sh16[i]);
+        double sv[R], qv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            double s_ = 0.0, q_ = 0.0;
+            if (bm > -INFINITY) {
+                if (l0[r] > -INFINITY) { const double e = exp(l0[r] - bm); s_ += e; q_ += e * e; }
+                if (l1[r] > -INFINITY) { const double e = exp(l1[r] - bm); s_ += e; q_ += e * e; }
+            }
+            sv[r] = wave_sum(s_); qv[r] = wave_sum(q_);
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) sh16[wave + (NT / 64) * r] = sv[r];
+        }
+        __syncthreads();
+        double S = 0.0;
+#pragma unroll
+        for (int i = 0; i < NTS / 64; i++) S += sh16[i];
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) sh16[wave + (NT / 64) * r] = qv[r];
+        }
+        __syncthreads();
+        double Q = 0.0;
+#pragma unroll
+        for (int i = 0; i < NTS / 64; i++) Q += sh16[i];
+        if (t == 0) { *pm = bm; *ps = S; *pq = Q; }
+    }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
+{
+    __shared__ SegSmem sm;
+    __shared__ uint64_t tin[NT];
+    __shared__ int Tl[EB];
+    __shared__ int Tbegin;
+    __shared__ double es[NT];
+    __shared__ double sh16[NTS / 64];
+    __shared__ __attribute__((aligned(16))) double XA[EB];
+    __shared__ __attribute__((aligned(16))) double XB[EB];
+    __shared__ __attribute__((aligned(16))) double LW[EB];      // log-weights, then (in place) the normalised weights
+    __shared__ DevState st;
+    __shared__ BlockRec br;
+    __shared__ double pm1, ps1, pq1, ainw1, ainp1, sep;
+    __shared__ uint64_t cin1;
+    const int fi = blockIdx.x, t = threadIdx.x;
+    const long long N = g.N;
+    const int T = g.T;
+    ModelPar par;
+    {
+        const double* th = g.theta + (long long)fi * g.theta_stride;
+        par.phi = th[0]; par.sx = th[1]; par.sy = th[2]; par.log_sy = log(th[2]);
+        par.n_total = 0.0; par.s0 = 0.0; par.i0 = 0.0; par.lgy = 0.0;
+    }
+    const PhiloxKey key = g.keys[fi];
+    if (t == 0) {
+        st.loglike = 0.0; st.lse_max = 0.0; st.lse_sum = 0.0; st.ess = 0.0; st.total_bits = 0;
+        st.do_resample = 0; st.dead = 0; st.flags = 0; st.res_calls = 0; st.cur_call = 0; st.debug_stop = 0;
+        st.stat_hard_blocks = 0; st.stat_serial_walks = 0; st.stat_literal_terms = 0;
+        sep = 0.0;
+    }
+    __syncthreads();
+    {   // t = 0  (R/particle_filter_core.R:76-116)
+        NoiseSrc ns; ns.arr = nullptr; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
+        init_block(sm.sh4, 0, XA, N, ns, &sep, MODEL, par);
+    }
+    __syncthreads();
+    if (t == 0 && g.state_est) { double s0 = 0.0; s0 += sep; g.state_est[(long long)fi * (T + 1)] = s0; }
+    double* xa = XA; double* xb = XB;
+    int ktrans = 0, prev_t = 0;
+    for (int i = 1; i <= T; i++) {                                                        // :123
+        const int ot = g.obs_times ? g.obs_times[i - 1] : i;
+        const int gap = ot - prev_t;                                                      // :124
+        prev_t = ot;
+        const double yi = g.y[i - 1];
+        NoiseSrc ns; ns.arr = nullptr; ns.key = key; ns.purpose = DRAW_TRANS;
+        for (int step = 1; step <= gap; step++) {                                         // :125-136
+            ns.call = (uint32_t)ktrans;
+            if (step == gap) step_emul<MODEL, true, 1>(sh16, xa, LW, N, par, yi, ns, &pm1, &ps1, &pq1);
+            else step_emul<MODEL, true, 0>(sh16, xa, LW, N, par, yi, ns, &pm1, &ps1, &pq1);
+            ktrans++;
+            __syncthreads();
+        }
+        if (gap <= 0) {                                  // obs_times repeats a time: weights on the current particles
+            ns.call = 0;
+            step_emul<MODEL, false, 1>(sh16, xa, LW, N, par, yi, ns, &pm1, &ps1, &pq1);
+            __syncthreads();
+        }
+        if (t == 0) sep = 0.0;
+        FromLw fl;
+        fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.ain_out = &ainw1;
+        fl.plan = PLAN_PF; fl.N = N; fl.obs_i = i; fl.resample_algorithm = g.resample_algorithm; fl.threshold = g.threshold;
+        fl.ess_out = g.ess + (long long)fi * (T + 1); fl.llh_out = g.llh + (long long)fi * T; fl.resampled_out = nullptr;
+        // normalise + loglik/ESS/decision + the exact sum(weights) of the block (:204-218, src/resampling.cpp:20-24)
+        local_block<MODE_W, true, NT>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fl);
+        __syncthreads();
+        if (t == 0 && !st.dead && !st.flags && st.do_resample) {      // what k_resolve<W> / k_resolve<P> come to for one block
+            const uint64_t fs = br.prefix.o[0];
+            const double tot = b2d(fs);
+            st.total_bits = fs;
+            if (tot == 0.0) st.flags |= FLAG_ZERO_SUM;
+            if (!isfinite(tot)) st.flags |= FLAG_NONFINITE;
+            ainp1 = ainw1 / tot; cin1 = 0;
+        }
+        __syncthreads();
+        ApplyArgs a;
+        a.w = LW; a.nw = N; a.ain_p = &ainp1; a.cin = &cin1; a.lim = g.lim; a.n = (int)N;
+        a.u_base = nullptr; a.u_stride = 0; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;
+        a.xsrc = xa; a.xdst = xb; a.dim = 1; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = &sep;
+        if (g.resample_fn == 1) apply_block<1>(sm, tin, Tl, Tbegin, 0, 1, a, &st);       // systematic
+        else apply_block<0>(sm, tin, Tl, Tbegin, 0, 1, a, &st);                           // stratified
+        __syncthreads();
+        if (g.resample_algorithm != 1) {                 // SIS / SISAR: carry over when no resample ran (:238)
+            carry_block(sm.sh4, 0, xa, xb, LW, N, 1, &sep, &st);
+            __syncthreads();
+        }
+        { double* tmp = xa; xa = xb; xb = tmp; }
+        if (t == 0 && g.state_est) { double s0 = 0.0; s0 += sep; g.state_est[(long long)fi * (T + 1) + i] = s0; }   // :237-241
+        if (st.dead) break;                              // degenerate weights: the reference returns at once (:189-202)
+        __syncthreads();
+    }
+    if (t == 0) { g.loglike[fi] = st.loglike; g.dead[fi] = st.dead; g.flags[fi] = st.flags; g.res_calls[fi] = st.res_calls; }
+}
+
 __global__ void k_reset_state(DevState* st)
 {
     st->loglike = 0.0; st->lse_max = 0.0; st->lse_sum = 0.0; st->ess = 0.0; st->total_bits = 0;

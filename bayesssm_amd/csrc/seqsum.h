@@ -110,6 +110,12 @@ BSSM_HD Rec chunk_record(const double* v, int L, int vs, double h, int32_t lim)
         return r;
     }
     const uint64_t hb = d2b(h) & ~3ull;
+    {   // a chunk of zeros (the padding past the last weight, or truly zero weights) leaves ANY state as it is: c + 0.0 == c.
+        // Without this, the padding lanes of a partly filled block sit next to cum == 1.0 and would all be HARD.
+        bool allzero = true;
+        for (int k = 0; k < L; k++) allzero = allzero && (v[k * vs] == 0.0);
+        if (allzero) { r.base = hb; r.kind = REC_PURE; r.lo = -lim; r.hi = lim; r.o[0] = hb; r.o[1] = hb + 1; r.o[2] = hb + 2; r.o[3] = hb + 3; return r; }
+    }
     const uint64_t near = (uint64_t)lim + 8;
     bool hard = near_pow2(hb, near);
     double c0 = b2d(hb), c1 = b2d(hb + 1), c2 = b2d(hb + 2), c3 = b2d(hb + 3);
@@ -153,6 +159,12 @@ BSSM_HD Rec chunk_record_fixed(const double (&v)[L], double h, int32_t lim)
         return r;
     }
     const uint64_t hb = d2b(h) & ~3ull;
+    {   // all-zero chunk: identity for any state (see chunk_record)
+        bool allzero = true;
+#pragma unroll
+        for (int k = 0; k < L; k++) allzero = allzero && (v[k] == 0.0);
+        if (allzero) { r.base = hb; r.kind = REC_PURE; r.lo = -lim; r.hi = lim; r.o[0] = hb; r.o[1] = hb + 1; r.o[2] = hb + 2; r.o[3] = hb + 3; return r; }
+    }
     const uint64_t near = (uint64_t)lim + 8;
     bool hard = near_pow2(hb, near);
     double c0 = b2d(hb), c1 = b2d(hb + 1), c2 = b2d(hb + 2), c3 = b2d(hb + 3);

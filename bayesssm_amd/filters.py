@@ -109,6 +109,61 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
     return out
 
 
+def batch_max_particles():
+    return int(_lib.load().bssm_pf_batch_max_particles())
+
+
+def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelihood_fn, thetas, seeds=0, streams=None,
+                           obs_times=None, resample_algorithm=None, resample_fn=None, threshold=None, ctx=None):
+    """Many independent bootstrap filters in ONE kernel launch (one workgroup per filter, the whole T loop on chip):
+    filter k runs with thetas[k] = (phi, sigma_x, sigma_y), seeds[k], streams[k] on the shared data `y`.  Each filter
+    returns exactly what bootstrap_filter(..., seed=seeds[k], stream=streams[k], return_particles=False) returns.
+    This is the shape of the reference's small-N workloads: the pilot's repeated runs (R/pmmh_tuning.R:111-151) and
+    PMMH chains advancing in lock-step (R/pmmh.R:445-457).  num_particles <= batch_max_particles().
+    Returns a dict of arrays: loglike [F], state_est [F, T+1], ess [F, T+1], loglike_history [F, T],
+    early_return_step [F], n_res_calls [F], status [F] (0 = ok) and device_ms."""
+    resample_algorithm = _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")
+    resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    if not (isinstance(num_particles, (int, np.integer)) and num_particles > 0):
+        raise ValueError("Assertion on 'num_particles' failed: Must be a positive count")
+    model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError("this build supports scalar observations (y a vector)")
+    if not np.all(np.isfinite(y)):
+        raise ValueError("Assertion on 'y' failed: Contains missing values")
+    T, N = int(y.size), int(num_particles)
+    ot = None
+    if obs_times is not None:
+        ot = np.ascontiguousarray(obs_times, dtype=np.int32)
+        if ot.size != T or (T and (ot[0] < 1 or np.any(np.diff(ot) < 0))):
+            raise ValueError("Assertion on 'obs_times' failed")
+    thetas = np.ascontiguousarray(thetas, dtype=np.float64)
+    if thetas.ndim != 2 or thetas.shape[1] < 3:
+        raise ValueError("thetas must be an (n_filters, 3) array of (phi, sigma_x, sigma_y)")
+    F = int(thetas.shape[0])
+    seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (F,)))
+    streams = np.arange(F, dtype=np.uint64) if streams is None else \
+        np.ascontiguousarray(np.broadcast_to(np.asarray(streams, dtype=np.uint64), (F,)))
+    ctx = ctx or _lib.default_context(N, dim=1)
+    ll = np.zeros(F)
+    se = np.zeros((F, T + 1))
+    ess = np.zeros((F, T + 1))
+    llh = np.zeros((F, max(T, 1)))
+    ers = np.zeros(F, dtype=np.int32)
+    nres = np.zeros(F, dtype=np.int32)
+    status = np.zeros(F, dtype=np.int32)
+    ms = np.zeros(1)
+    cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM["BPF"], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
+                        _lib.RESAMPLE_FN[resample_fn], N, T, -1.0 if threshold is None else float(threshold),
+                        None, int(thetas.shape[1]), _ptr(y), _ptr(ot), 0, 0, None, None, None, 0, 0, 0.0, None, None)
+    res = _lib.PfBatchResult(_ptr(ll), _ptr(se), _ptr(ess), _ptr(llh), _ptr(ers), _ptr(nres), _ptr(status), _ptr(ms))
+    _lib.check(_lib.load().bssm_pf_run_batch(ctx.handle, C.byref(cfg), F, _ptr(thetas), _ptr(seeds), _ptr(streams),
+                                             C.byref(res)))
+    return {"loglike": ll, "state_est": se, "ess": ess, "loglike_history": llh[:, :T], "early_return_step": ers,
+            "n_res_calls": nres, "status": status, "device_ms": float(ms[0]), "algorithm": "BPF"}
+
+
 def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn, obs_times=None,
                      resample_algorithm=None, resample_fn=None, threshold=None, return_particles=True, **kwargs):
     """bootstrap_filter (R/bootstrap_filter.R:129-171).  Model parameters are passed by name

@@ -162,6 +162,28 @@ typedef struct {
 
 int bssm_pf_run(bssm_ctx* ctx, const bssm_pf_config* cfg, bssm_pf_result* res);
 
+/* ---- many small filters per launch ----------------------------------------
+ * The reference runs its filters at N <= 1000 inside PMMH (R/pmmh.R:403-415,445-457) and 100 of them at N = 100 in the
+ * pilot (R/pmmh_tuning.R:111-151): launch-bound one at a time.  bssm_pf_run_batch runs n_filters independent bootstrap
+ * filters -- same data and settings (cfg), one theta / seed / stream each -- in ONE kernel launch, one workgroup per
+ * filter with the whole T loop on chip.  Each filter's outputs are bit-identical to bssm_pf_run with that theta, seed
+ * and stream.  Limits: num_particles <= bssm_pf_batch_max_particles() (2048), BPF, LG / AR1SIN models, stratified or
+ * systematic resampling, device generator only (cfg->theta, seed, stream, z_*, u_res, return_* are not used). */
+typedef struct {
+    double* loglike;          /* [n_filters]                                                    */
+    double* state_est;        /* [n_filters][T+1] or NULL                                       */
+    double* ess;              /* [n_filters][T+1] or NULL                                       */
+    double* loglike_history;  /* [n_filters][T]   or NULL                                       */
+    int* early_return_step;   /* [n_filters] or NULL                                            */
+    int* n_res_calls;         /* [n_filters] or NULL                                            */
+    int* status;              /* [n_filters] or NULL: per-filter BSSM_* status; when NULL the first failure is returned */
+    double* device_ms;        /* 1 or NULL                                                      */
+} bssm_pf_batch_result;
+
+int bssm_pf_batch_max_particles(void);
+int bssm_pf_run_batch(bssm_ctx* ctx, const bssm_pf_config* cfg, int n_filters, const double* thetas /* [n_filters][cfg->n_theta] */,
+                      const unsigned long long* seeds, const unsigned long long* streams, bssm_pf_batch_result* res);
+
 /* Number of transition_fn / resample calls the filter makes at most (sizes of
  * the injected-draw arrays and of `ancestors`). */
 int bssm_pf_noise_shape(int algorithm, int T, const int* obs_times, int* max_trans, int* max_res);

@@ -1,0 +1,101 @@
+"""Batched small filters (one workgroup = one whole filter, bssm_pf_run_batch) against the multi-launch path
+(bssm_pf_run), which the other GPU tests hold to the oracle.  The batched kernel re-enacts the multi-launch
+arithmetic call for call, so every output must agree BIT FOR BIT -- log-likelihoods, ESS, state estimates."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(T, seed=1405):
+    rng = np.random.default_rng(seed)
+    x, ys = rng.standard_normal(), np.empty(T)
+    for t in range(T):
+        x = 0.8 * x + rng.standard_normal()
+        ys[t] = x + 0.7 * rng.standard_normal()
+    return ys
+
+
+def _single(b, m, y, N, th, seed, stream, **kw):
+    return b.bootstrap_filter(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, return_particles=False,
+                              seed=seed, stream=stream, phi=th[0], sigma_x=th[1], sigma_y=th[2], **kw)
+
+
+@pytest.mark.parametrize("model", ["lg", "ar1sin"])
+@pytest.mark.parametrize("N", [1, 7, 100, 1000, 2047, 2048])
+@pytest.mark.parametrize("ra,rf", [("SISR", "systematic"), ("SISAR", "stratified"), ("SIS", "stratified"), ("SISR", "stratified")])
+def test_batch_matches_single_bitwise(model, N, ra, rf):
+    import bayesssm_amd as b
+    m = b.models.linear_gaussian() if model == "lg" else b.models.ar1_sin()
+    T = 25
+    y = _data(T)
+    rng = np.random.default_rng(N)
+    F = 5
+    thetas = np.column_stack([rng.uniform(0.3, 0.95, F), rng.uniform(0.5, 1.5, F), rng.uniform(0.4, 1.2, F)])
+    seeds = np.array([11, 11, 12, 13, 2 ** 40 + 5], dtype=np.uint64)
+    streams = np.array([0, 1, 7, 2 ** 33 + 3, 9], dtype=np.uint64)
+    out = b.bootstrap_filter_batch(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, seeds, streams,
+                                   resample_algorithm=ra, resample_fn=rf)
+    assert np.all(out["status"] == 0)
+    for k in range(F):
+        ref = _single(b, m, y, N, thetas[k], int(seeds[k]), int(streams[k]), resample_algorithm=ra, resample_fn=rf)
+        assert out["loglike"][k] == ref["loglike"], (k, out["loglike"][k], ref["loglike"])
+        np.testing.assert_array_equal(out["loglike_history"][k], ref["loglike_history"])
+        np.testing.assert_array_equal(out["ess"][k], ref["ess"])
+        np.testing.assert_array_equal(out["state_est"][k], ref["state_est"])
+        assert out["n_res_calls"][k] == ref["_extras"]["n_res_calls"]
+
+
+def test_batch_obs_times_gaps_and_threshold():
+    import bayesssm_amd as b
+    m = b.models.linear_gaussian()
+    y = _data(12)
+    ot = np.array([1, 2, 2, 5, 6, 9, 10, 11, 11, 14, 15, 16], dtype=np.int32)
+    thetas = np.array([[0.8, 1.0, 0.7], [0.5, 0.6, 1.1]])
+    out = b.bootstrap_filter_batch(y, 300, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 5, [3, 4],
+                                   obs_times=ot, resample_algorithm="SISAR", resample_fn="systematic", threshold=120.0)
+    for k in range(2):
+        ref = _single(b, m, y, 300, thetas[k], 5, 3 + k, obs_times=ot, resample_algorithm="SISAR",
+                      resample_fn="systematic", threshold=120.0)
+        assert out["loglike"][k] == ref["loglike"]
+        np.testing.assert_array_equal(out["ess"][k], ref["ess"])
+        np.testing.assert_array_equal(out["state_est"][k], ref["state_est"])
+
+
+def test_batch_degenerate_early_return():
+    import bayesssm_amd as b
+    m = b.models.linear_gaussian()
+    y = _data(10)
+    y[4] = 1e6                              # every log-weight < -1e8 at observation 5 for a narrow sigma_y
+    thetas = np.array([[0.8, 1.0, 0.05], [0.8, 1.0, 1e5]])
+    out = b.bootstrap_filter_batch(y, 64, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 1, [0, 1],
+                                   resample_algorithm="SISR", resample_fn="systematic")
+    assert out["early_return_step"][0] == 5 and out["loglike"][0] == -np.inf
+    assert out["early_return_step"][1] == 0 and np.isfinite(out["loglike"][1])
+    for k in range(2):
+        ref = _single(b, m, y, 64, thetas[k], 1, k, resample_algorithm="SISR", resample_fn="systematic")
+        assert out["loglike"][k] == ref["loglike"]
+        np.testing.assert_array_equal(out["loglike_history"][k], ref["loglike_history"])
+        np.testing.assert_array_equal(out["ess"][k], ref["ess"])
+        np.testing.assert_array_equal(out["state_est"][k], ref["state_est"])
+
+
+def test_batch_many_filters_and_limits():
+    import bayesssm_amd as b
+    m = b.models.linear_gaussian()
+    y = _data(40)
+    F = 600                                  # more workgroups than fit on the chip at once
+    thetas = np.tile([0.8, 1.0, 0.7], (F, 1))
+    out = b.bootstrap_filter_batch(y, 100, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 1405,
+                                   resample_algorithm="SISR", resample_fn="stratified")
+    assert np.all(np.isfinite(out["loglike"])) and len(set(out["loglike"].tolist())) == F   # distinct streams
+    kal = __import__("oracle.oracle", fromlist=["kalman_loglik"]).kalman_loglik(y, 0.8, 1.0, 0.7)
+    # the mean of exp(loglik - kalman) over filters estimates 1 (SISR: unbiased likelihood estimator; with SISAR the
+    # reference drops the weights of un-resampled steps, R/particle_filter_core.R:204-209, and the estimator is biased)
+    r = np.exp(out["loglike"] - kal)
+    assert abs(r.mean() - 1.0) < 5 * r.std() / np.sqrt(F) + 0.05
+    ref = _single(b, m, y, 100, thetas[17], 1405, 17, resample_algorithm="SISR", resample_fn="stratified")
+    assert out["loglike"][17] == ref["loglike"]
+    assert b.batch_max_particles() == 2048
+    with pytest.raises(Exception):
+        b.bootstrap_filter_batch(y, 2049, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas[:2], 1)
