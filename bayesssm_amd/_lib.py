@@ -105,6 +105,7 @@ def load():
     lib.bssm_dump_uniforms.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_longlong, C.c_void_p]
     lib.bssm_dump_move_draws.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
     lib.bssm_pmmh_chain.argtypes = [C.c_void_p, C.POINTER(PmmhConfig), C.POINTER(PmmhResult)]
+    lib.bssm_pmmh_chains_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.bssm_pf_run_batch.argtypes = [C.c_void_p, C.POINTER(PfConfig), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(PfBatchResult)]
     _lib = lib
@@ -117,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "bssm_resample_multinomial", "bssm_resample_device", "bssm_resample_device_status", "bssm_resample_ex",
     "bssm_pf_run", "bssm_pf_noise_shape", "bssm_dump_normals", "bssm_dump_uniforms", "bssm_dump_move_draws",
     "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_pmmh_chain",
-    "bssm_pf_run_batch", "bssm_pf_batch_max_particles",
+    "bssm_pf_run_batch", "bssm_pf_batch_max_particles", "bssm_pmmh_chains_batch",
 ]
 
 

@@ -682,6 +682,8 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (cfg->obs_times && (rc = pool_get(c, "b_ot", (size_t)std::max(T, 1) * 4, &d_ot))) return rc;
     if ((rc = pool_get(c, "b_th", (size_t)F * nth * 8, &d_th))) return rc;
     if ((rc = pool_get(c, "b_keys", (size_t)F * sizeof(PhiloxKey), &d_keys))) return rc;
+    void* d_lsy;
+    if ((rc = pool_get(c, "b_lsy", (size_t)F * 8, &d_lsy))) return rc;
     if ((rc = pool_get(c, "b_ll", (size_t)F * 8, &d_ll))) return rc;
     if ((rc = pool_get(c, "b_se", rowsT1, &d_se))) return rc;
     if ((rc = pool_get(c, "b_ess", rowsT1, &d_ess))) return rc;
@@ -690,7 +692,9 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if ((rc = pool_get(c, "b_flags", (size_t)F * 4, &d_flags))) return rc;
     if ((rc = pool_get(c, "b_res", (size_t)F * 4, &d_res))) return rc;
     std::vector<PhiloxKey> keys((size_t)F);
-    for (int f = 0; f < F; f++) keys[f] = make_key(seeds[f], streams[f]);
+    std::vector<double> lsy((size_t)F);
+    for (int f = 0; f < F; f++) { keys[f] = make_key(seeds[f], streams[f]); lsy[f] = log(thetas[(size_t)f * nth + 2]); }
+    HIPCHK(hipMemcpyAsync(d_lsy, lsy.data(), (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
     if (T > 0) HIPCHK(hipMemcpyAsync(d_y, cfg->y, (size_t)T * 8, hipMemcpyHostToDevice, c->stream));
     if (d_ot && T > 0) HIPCHK(hipMemcpyAsync(d_ot, cfg->obs_times, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_th, thetas, (size_t)F * nth * 8, hipMemcpyHostToDevice, c->stream));
@@ -702,7 +706,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     g.N = (int)N; g.T = T; g.resample_algorithm = cfg->resample_algorithm; g.resample_fn = cfg->resample_fn;
     g.lim = g_debug_lim > 0 ? g_debug_lim : rec_window(N);
     g.threshold = threshold; g.y = (const double*)d_y; g.obs_times = (const int*)d_ot;
-    g.theta = (const double*)d_th; g.theta_stride = nth; g.keys = (const PhiloxKey*)d_keys;
+    g.theta = (const double*)d_th; g.theta_stride = nth; g.log_sy = (const double*)d_lsy; g.keys = (const PhiloxKey*)d_keys;
     g.loglike = (double*)d_ll; g.state_est = (double*)d_se; g.ess = (double*)d_ess; g.llh = (double*)d_llh;
     g.dead = (int*)d_dead; g.flags = (uint32_t*)d_flags; g.res_calls = (int*)d_res;
     HIPCHK(hipEventRecord(c->ev0, c->stream));
@@ -773,72 +777,76 @@ static double tr_fwd(int tr, double x) { return tr == BSSM_TR_LOG ? log(x) : tr 
 static double tr_back(int tr, double z) { return tr == BSSM_TR_LOG ? exp(z) : tr == BSSM_TR_LOGIT ? 1 / (1 + exp(-z)) : z; }        // R/utils.R:122-132
 static double tr_logjac(int tr, double x) { return tr == BSSM_TR_LOG ? log(x) : tr == BSSM_TR_LOGIT ? log(1 / (x * (1 - x))) : 0.0; }  // R/utils.R:142-152
 
-extern "C" int bssm_pmmh_chain(bssm_ctx* c, const bssm_pmmh_config* cfg, bssm_pmmh_result* res)
-{
-    if (!c || !cfg || !res) ARGFAIL("bssm_pmmh_chain: NULL argument");
-    const int p = cfg->n_params, m = cfg->m, T = cfg->pf.T;
-    if (p < 1 || p > 16) ARGFAIL("bssm_pmmh_chain: n_params out of range");
-    if (m < 1) ARGFAIL("Assertion on 'm' failed: Must be >= 1");                         // assert_int(m, lower = 1) R/pmmh.R:264
-    if (!cfg->init_theta || !cfg->proposal_cov || !cfg->transform || !cfg->prior_kind || !cfg->prior_a || !cfg->prior_b)
-        ARGFAIL("bssm_pmmh_chain: NULL configuration array");
-    if (!res->theta_chain) ARGFAIL("bssm_pmmh_chain: theta_chain buffer missing");
-    // proposal covariance on the transformed scale: J Sigma J, J = diag(dz/dtheta at init_theta)   R/pmmh.R:378-389
-    std::vector<double> scale(p), cov(p * p), L(p * p, 0.0);
-    for (int j = 0; j < p; j++) {
-        const double th = cfg->init_theta[j];
-        scale[j] = cfg->transform[j] == BSSM_TR_LOG ? 1 / th : cfg->transform[j] == BSSM_TR_LOGIT ? 1 / (th * (1 - th)) : 1.0;
-    }
-    for (int a = 0; a < p; a++) for (int b = 0; b < p; b++) cov[a * p + b] = scale[a] * cfg->proposal_cov[a * p + b] * scale[b];
-    // mvrnorm(1, mu, Sigma): Cholesky factor here (MASS uses an eigen-decomposition; same law)
-    for (int a = 0; a < p; a++) {
-        for (int b = 0; b <= a; b++) {
-            double s = cov[a * p + b];
-            for (int k = 0; k < b; k++) s -= L[a * p + k] * L[b * p + k];
-            if (a == b) { if (!(s > 0)) ARGFAIL("'Sigma' is not positive definite"); L[a * p + a] = sqrt(s); }
-            else L[a * p + b] = s / L[b * p + b];
+// One chain's Metropolis-Hastings state: everything of R/pmmh.R:345-505 except the filter run itself, so that the
+// same code drives one chain over bssm_pf_run and many chains in lock-step over bssm_pf_run_batch.
+struct ChainState {
+    const bssm_pmmh_config* cfg; bssm_pmmh_result* res;
+    int p, m, T, dim, n_full;
+    std::vector<double> L, cur, prop, lp_prop, th_full, se_cur, se_prop;
+    PhiloxKey ckey;
+    double cur_ll; int accepted;
+
+    int init(const bssm_pmmh_config* cfg_, bssm_pmmh_result* res_)
+    {
+        cfg = cfg_; res = res_;
+        if (!cfg || !res) ARGFAIL("bssm_pmmh_chain: NULL argument");
+        p = cfg->n_params; m = cfg->m; T = cfg->pf.T;
+        if (p < 1 || p > 16) ARGFAIL("bssm_pmmh_chain: n_params out of range");
+        if (m < 1) ARGFAIL("Assertion on 'm' failed: Must be >= 1");                         // assert_int(m, lower = 1) R/pmmh.R:264
+        if (!cfg->init_theta || !cfg->proposal_cov || !cfg->transform || !cfg->prior_kind || !cfg->prior_a || !cfg->prior_b)
+            ARGFAIL("bssm_pmmh_chain: NULL configuration array");
+        if (!res->theta_chain) ARGFAIL("bssm_pmmh_chain: theta_chain buffer missing");
+        // proposal covariance on the transformed scale: J Sigma J, J = diag(dz/dtheta at init_theta)   R/pmmh.R:378-389
+        std::vector<double> scale(p), cov(p * p);
+        L.assign((size_t)p * p, 0.0);
+        for (int j = 0; j < p; j++) {
+            const double th = cfg->init_theta[j];
+            scale[j] = cfg->transform[j] == BSSM_TR_LOG ? 1 / th : cfg->transform[j] == BSSM_TR_LOGIT ? 1 / (th * (1 - th)) : 1.0;
         }
+        for (int a = 0; a < p; a++) for (int b = 0; b < p; b++) cov[a * p + b] = scale[a] * cfg->proposal_cov[a * p + b] * scale[b];
+        // mvrnorm(1, mu, Sigma): Cholesky factor here (MASS uses an eigen-decomposition; same law)
+        for (int a = 0; a < p; a++) {
+            for (int b = 0; b <= a; b++) {
+                double s = cov[a * p + b];
+                for (int k = 0; k < b; k++) s -= L[a * p + k] * L[b * p + k];
+                if (a == b) { if (!(s > 0)) ARGFAIL("'Sigma' is not positive definite"); L[a * p + a] = sqrt(s); }
+                else L[a * p + b] = s / L[b * p + b];
+            }
+        }
+        ckey = make_key(cfg->seed, 0x50000000ull + (unsigned long long)cfg->chain_index);
+        cur.assign(cfg->init_theta, cfg->init_theta + p); prop.assign(p, 0.0); lp_prop.assign(p, 0.0);
+        dim = (cfg->pf.model == BSSM_MODEL_SIR) ? 2 : 1;
+        n_full = std::max(cfg->pf.n_theta, p);               // sampled parameters first, then fixed model constants
+        th_full.assign((size_t)n_full, 0.0);
+        for (int j = p; j < n_full; j++) th_full[j] = cfg->pf.theta ? cfg->pf.theta[j] : 0.0;
+        se_cur.assign(((size_t)T + 1) * dim, 0.0); se_prop.assign(((size_t)T + 1) * dim, 0.0);
+        cur_ll = 0; accepted = 0;
+        return BSSM_OK;
     }
-    const PhiloxKey ckey = make_key(cfg->seed, 0x50000000ull + (unsigned long long)cfg->chain_index);
-    std::vector<double> cur(cfg->init_theta, cfg->init_theta + p), prop(p), z(p), ztr(p), lp_prop(p);
-    const int dim = (cfg->pf.model == BSSM_MODEL_SIR) ? 2 : 1;
-    const int n_full = std::max(cfg->pf.n_theta, p);            // sampled parameters first, then fixed model constants
-    std::vector<double> th_full((size_t)n_full, 0.0);
-    for (int j = p; j < n_full; j++) th_full[j] = cfg->pf.theta ? cfg->pf.theta[j] : 0.0;
-    std::vector<double> se_cur(((size_t)T + 1) * dim), se_prop(((size_t)T + 1) * dim), ess((size_t)T + 1), llh((size_t)std::max(T, 1));
-    double ll = 0, ms = 0, ms_total = 0;
-    int ers = 0, nres = 0;
-    bssm_pf_config pf = cfg->pf;
-    pf.n_theta = n_full; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
-    pf.seed = cfg->seed;
-    bssm_pf_result pr; memset(&pr, 0, sizeof(pr));
-    pr.scan_stats = nullptr; pr.ess = ess.data(); pr.loglike_history = llh.data(); pr.loglike = &ll; pr.early_return_step = &ers; pr.n_res_calls = &nres; pr.device_ms = &ms;
-    auto run_pf = [&](const std::vector<double>& th, std::vector<double>& se, unsigned iter) -> int {
-        for (int j = 0; j < p; j++) th_full[j] = th[j];
-        pf.theta = th_full.data(); pr.state_est = se.data();
-        pf.stream = ((unsigned long long)cfg->chain_index << 32) | iter;
-        const int rc = bssm_pf_run(c, &pf, &pr);
-        ms_total += ms;
-        return rc;
-    };
-    int rc = run_pf(cur, se_cur, 0);                                                     // R/pmmh.R:403-417
-    if (rc) return rc;
-    double cur_ll = ll;
-    int accepted = 0;
-    auto store = [&](int i) {
+    // the filter's theta / stream for iteration `iter` with parameters `th`
+    const double* full_theta(const std::vector<double>& th) { for (int j = 0; j < p; j++) th_full[j] = th[j]; return th_full.data(); }
+    unsigned long long stream_of(unsigned iter) const { return ((unsigned long long)cfg->chain_index << 32) | iter; }
+    void store(int i)
+    {
         for (int j = 0; j < p; j++) res->theta_chain[(size_t)i * p + j] = cur[j];
         if (res->loglike_chain) res->loglike_chain[i] = cur_ll;
         if (res->state_est_chain) memcpy(res->state_est_chain + (size_t)i * (T + 1) * dim, se_cur.data(), sizeof(double) * (T + 1) * dim);
-    };
-    store(0);
-    for (int i = 1; i < m; i++) {                                                        // for (i in 2:m)  R/pmmh.R:422
+    }
+    void start(double ll0) { cur_ll = ll0; store(0); }                                       // R/pmmh.R:403-417 (se_cur filled by the caller)
+    // draw the proposal of iteration i (:424-432); false = a prior is -Inf, the chain stays put and no filter runs (:435-442)
+    bool propose(int i)
+    {
+        std::vector<double> z(p), ztr(p);
         for (int j = 0; j < p; j++) { ztr[j] = tr_fwd(cfg->transform[j], cur[j]); z[j] = host_normal(ckey, (uint32_t)i, (uint32_t)j); }
-        for (int a = 0; a < p; a++) { double s = ztr[a]; for (int k = 0; k <= a; k++) s += L[a * p + k] * z[k]; prop[a] = tr_back(cfg->transform[a], s); }   // :424-432
+        for (int a = 0; a < p; a++) { double s = ztr[a]; for (int k = 0; k <= a; k++) s += L[a * p + k] * z[k]; prop[a] = tr_back(cfg->transform[a], s); }
         bool finite = true;
         for (int j = 0; j < p; j++) { lp_prop[j] = log_prior(cfg->prior_kind[j], cfg->prior_a[j], cfg->prior_b[j], prop[j]); if (!isfinite(lp_prop[j])) finite = false; }
-        if (!finite) { store(i); continue; }                                             // :435-442
-        rc = run_pf(prop, se_prop, (unsigned)i);                                         // :445-457
-        if (rc) return rc;
-        const double prop_ll = ll;
+        if (!finite) store(i);
+        return finite;
+    }
+    // accept / reject with the proposal's log-likelihood (se_prop filled by the caller)   :461-496
+    void finish(int i, double prop_ll)
+    {
         double lj_prop = 0, lj_cur = 0, slp_prop = 0, slp_cur = 0;
         for (int j = 0; j < p; j++) {
             lj_prop += tr_logjac(cfg->transform[j], prop[j]); lj_cur += tr_logjac(cfg->transform[j], cur[j]);   // :461-469
@@ -849,7 +857,93 @@ extern "C" int bssm_pmmh_chain(bssm_ctx* c, const bssm_pmmh_config* cfg, bssm_pm
         if (log(host_uniform(ckey, (uint32_t)i)) < lar) { cur = prop; cur_ll = prop_ll; se_cur = se_prop; accepted++; }   // :492-496
         store(i);
     }
-    if (res->accepted) *res->accepted = accepted;
+};
+
+extern "C" int bssm_pmmh_chain(bssm_ctx* c, const bssm_pmmh_config* cfg, bssm_pmmh_result* res)
+{
+    if (!c) ARGFAIL("bssm_pmmh_chain: NULL argument");
+    ChainState ch;
+    int rc = ch.init(cfg, res);
+    if (rc) return rc;
+    const int T = ch.T, m = ch.m;
+    std::vector<double> ess((size_t)T + 1), llh((size_t)std::max(T, 1));
+    double ll = 0, ms = 0, ms_total = 0;
+    int ers = 0, nres = 0;
+    bssm_pf_config pf = cfg->pf;
+    pf.n_theta = ch.n_full; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
+    pf.seed = cfg->seed;
+    bssm_pf_result pr; memset(&pr, 0, sizeof(pr));
+    pr.scan_stats = nullptr; pr.ess = ess.data(); pr.loglike_history = llh.data(); pr.loglike = &ll; pr.early_return_step = &ers; pr.n_res_calls = &nres; pr.device_ms = &ms;
+    auto run_pf = [&](const std::vector<double>& th, std::vector<double>& se, unsigned iter) -> int {
+        pf.theta = ch.full_theta(th); pr.state_est = se.data();
+        pf.stream = ch.stream_of(iter);
+        const int rc2 = bssm_pf_run(c, &pf, &pr);
+        ms_total += ms;
+        return rc2;
+    };
+    rc = run_pf(ch.cur, ch.se_cur, 0);                                                   // R/pmmh.R:403-417
+    if (rc) return rc;
+    ch.start(ll);
+    for (int i = 1; i < m; i++) {                                                        // for (i in 2:m)  R/pmmh.R:422
+        if (!ch.propose(i)) continue;
+        rc = run_pf(ch.prop, ch.se_prop, (unsigned)i);                                   // :445-457
+        if (rc) return rc;
+        ch.finish(i, ll);
+    }
+    if (res->accepted) *res->accepted = ch.accepted;
     if (res->device_ms) *res->device_ms = ms_total;
+    return BSSM_OK;
+}
+
+// Many chains in lock-step: iteration i of every chain proposes, ONE batched launch runs all the proposals' filters
+// (one workgroup each), every chain accepts or rejects.  Chain k's result is exactly bssm_pmmh_chain's for cfgs[k]:
+// chain draws are keyed by (seed, chain_index) and the batched filters are bit-identical to bssm_pf_run.
+extern "C" int bssm_pmmh_chains_batch(bssm_ctx* c, int n_chains, const bssm_pmmh_config* cfgs, bssm_pmmh_result* ress)
+{
+    if (!c || !cfgs || !ress) ARGFAIL("bssm_pmmh_chains_batch: NULL argument");
+    if (n_chains < 1) ARGFAIL("bssm_pmmh_chains_batch: n_chains must be positive");
+    std::vector<ChainState> ch((size_t)n_chains);
+    for (int k = 0; k < n_chains; k++) { const int rc = ch[k].init(&cfgs[k], &ress[k]); if (rc) return rc; }
+    const bssm_pf_config& pf0 = cfgs[0].pf;
+    const int T = ch[0].T, m = ch[0].m, nth = ch[0].n_full;
+    for (int k = 1; k < n_chains; k++) {
+        const bssm_pf_config& q = cfgs[k].pf;
+        if (ch[k].m != m || ch[k].T != T || ch[k].n_full != nth || q.model != pf0.model || q.algorithm != pf0.algorithm ||
+            q.num_particles != pf0.num_particles || q.resample_algorithm != pf0.resample_algorithm || q.resample_fn != pf0.resample_fn ||
+            q.threshold != pf0.threshold || q.y != pf0.y || q.obs_times != pf0.obs_times)
+            ARGFAIL("bssm_pmmh_chains_batch: the chains must share the data, the filter settings and m");
+    }
+    bssm_pf_config pf = pf0;
+    pf.n_theta = nth; pf.theta = nullptr; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
+    std::vector<double> thetas((size_t)n_chains * nth), ll((size_t)n_chains), se((size_t)n_chains * (T + 1));
+    std::vector<unsigned long long> seeds((size_t)n_chains), streams((size_t)n_chains);
+    std::vector<int> who((size_t)n_chains);
+    double ms = 0, ms_total = 0;
+    bssm_pf_batch_result br; memset(&br, 0, sizeof(br));
+    br.loglike = ll.data(); br.state_est = se.data(); br.device_ms = &ms;
+    for (int i = 0; i < m; i++) {
+        int F = 0;
+        for (int k = 0; k < n_chains; k++) {
+            const bool run = (i == 0) ? true : ch[k].propose(i);
+            if (!run) continue;
+            const double* th = ch[k].full_theta(i == 0 ? ch[k].cur : ch[k].prop);
+            for (int j = 0; j < nth; j++) thetas[(size_t)F * nth + j] = th[j];
+            seeds[F] = cfgs[k].seed; streams[F] = ch[k].stream_of((unsigned)i); who[F] = k; F++;
+        }
+        if (F == 0) continue;
+        const int rc = bssm_pf_run_batch(c, &pf, F, thetas.data(), seeds.data(), streams.data(), &br);
+        if (rc) return rc;
+        ms_total += ms;
+        for (int f = 0; f < F; f++) {
+            ChainState& s = ch[who[f]];
+            std::vector<double>& dst = (i == 0) ? s.se_cur : s.se_prop;
+            memcpy(dst.data(), se.data() + (size_t)f * (T + 1), sizeof(double) * (T + 1));
+            if (i == 0) s.start(ll[f]); else s.finish(i, ll[f]);
+        }
+    }
+    for (int k = 0; k < n_chains; k++) {
+        if (ress[k].accepted) *ress[k].accepted = ch[k].accepted;
+        if (ress[k].device_ms) *ress[k].device_ms = ms_total / n_chains;
+    }
     return BSSM_OK;
 }

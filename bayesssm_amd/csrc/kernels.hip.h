@@ -1745,6 +1745,7 @@ struct BatchArgs {
     double threshold;
     const double* y; const int* obs_times;            // [T]; obs_times may be nullptr (1..T)
     const double* theta; int theta_stride;            // [F][theta_stride]: phi, sigma_x, sigma_y
+    const double* log_sy;                             // [F] log(sigma_y), taken on the host like bssm_pf_run does (device log may differ in the last bit)
     const PhiloxKey* keys;                            // [F]
     double* loglike; double* state_est; double* ess; double* llh;    // [F], [F][T+1], [F][T+1], [F][T]
     int* dead; uint32_t* flags; int* res_calls;       // [F]
@@ -1848,7 +1849,7 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
     ModelPar par;
     {
         const double* th = g.theta + (long long)fi * g.theta_stride;
-        par.phi = th[0]; par.sx = th[1]; par.sy = th[2]; par.log_sy = log(th[2]);
+        par.phi = th[0]; par.sx = th[1]; par.sy = th[2]; par.log_sy = g.log_sy[fi];
         par.n_total = 0.0; par.s0 = 0.0; par.i0 = 0.0; par.lgy = 0.0;
     }
     const PhiloxKey key = g.keys[fi];

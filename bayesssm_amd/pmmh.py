@@ -97,10 +97,12 @@ def _log_jacobian(theta, tr):
                      for t, k in zip(theta, tr)))
 
 
-def pilot_run(pf, pilot_n, pilot_reps):
+def pilot_run(pf, pilot_n, pilot_reps, pf_batch=None):
     """.pilot_run (R/pmmh_tuning.R:29-64): repeat the filter `pilot_reps` times at `pilot_n` particles and size
-    the main chain's particle count from the variance of the log-likelihood estimates."""
-    lls = np.array([pf(pilot_n, rep) for rep in range(pilot_reps)])
+    the main chain's particle count from the variance of the log-likelihood estimates.  `pf_batch(n, reps)`, when
+    given, returns all the repetitions' log-likelihoods from ONE batched launch (same values as pf(n, rep))."""
+    lls = np.asarray(pf_batch(pilot_n, list(range(pilot_reps)))) if pf_batch is not None else \
+        np.array([pf(pilot_n, rep) for rep in range(pilot_reps)])
     variance_estimate = float(np.var(lls, ddof=1))
     target_n = int(np.ceil(pilot_n * variance_estimate)) if np.isfinite(variance_estimate) else 1000
     target_n = min(max(target_n, 50), 1000)                                   # :55-57
@@ -108,7 +110,7 @@ def pilot_run(pf, pilot_n, pilot_reps):
 
 
 def run_pilot_chain(pf, pilot_m, pilot_n, pilot_reps, priors, proposal_sd, transform, pilot_init_params, rng,
-                    verbose=False, message=print):
+                    verbose=False, message=print, pf_batch=None):
     """.run_pilot_chain (R/pmmh_tuning.R:111-317): random-walk MH with independent normal proposals on the
     transformed scale, burn-in = half, posterior mean / covariance, then .pilot_run at the posterior mean.
     `pf(theta, n, tag)` runs one filter and returns its log-likelihood; host draws come from `rng`."""
@@ -148,7 +150,8 @@ def run_pilot_chain(pf, pilot_m, pilot_n, pilot_reps, priors, proposal_sd, trans
     if verbose:
         message("Pilot chain posterior mean:")
         message(str(mean))
-    pr_ = pilot_run(lambda n, rep: pf(mean, n, 10_000_000 + rep), pilot_n, pilot_reps)
+    pr_ = pilot_run(lambda n, rep: pf(mean, n, 10_000_000 + rep), pilot_n, pilot_reps,
+                    (lambda n, reps: pf_batch(mean, n, [10_000_000 + r for r in reps])) if pf_batch is not None else None)
     message("Using %d particles for PMMH:" % pr_["target_n"])                                  # :308
     return {"pilot_theta_mean": mean, "pilot_theta_cov": cov, "target_n": pr_["target_n"],
             "pilot_theta_chain": chain, "pilot_loglike_chain": llc, "variance_estimate": pr_["variance_estimate"]}
@@ -221,6 +224,54 @@ def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov
     _lib.check(_lib.load().bssm_pmmh_chain(ctx.handle, C.byref(cfg), C.byref(res)))
     return {"theta_chain": theta_chain, "loglike_chain": ll_chain, "state_est_chain": se_chain,
             "accepted": int(acc[0]), "device_ms": float(ms[0])}
+
+
+def batch_eligible(pf_wrapper, model, num_particles, resample_fn):
+    """Can this filter configuration run in the one-workgroup-per-filter kernel (bssm_pf_run_batch)?"""
+    from .filters import batch_max_particles
+    return (pf_wrapper is not auxiliary_filter and models.dim_of(model) == 1 and model in ("lg", "ar1sin")
+            and resample_fn in ("stratified", "systematic") and int(num_particles) <= batch_max_particles())
+
+
+def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, proposal_covs, transform, priors,
+                            num_particles, seeds, chain_indices, obs_times=None, resample_algorithm="SISAR",
+                            resample_fn="stratified", return_latent_state_est=False, ctx=None, model_constants=None):
+    """Several chains in lock-step (bssm_pmmh_chains_batch): iteration i of every chain is one kernel launch, one
+    workgroup per chain.  Chain k's result equals run_chain_device(...) with the k-th start, covariance, seed and
+    chain index -- bit for bit."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    T, K = y.size, len(chain_indices)
+    ctx = ctx or _lib.default_context(num_particles)
+    ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None   # noqa: E731
+    tr = np.ascontiguousarray([_lib.TRANSFORM[t] for t in transform], dtype=np.int32)
+    pk = np.ascontiguousarray([_lib.PRIOR[p.kind] for p in priors], dtype=np.int32)
+    pa = np.ascontiguousarray([p.a for p in priors], dtype=np.float64)
+    pb = np.ascontiguousarray([p.b for p in priors], dtype=np.float64)
+    keep, cfgs, ress, outs = [], [], [], []
+    for k in range(K):
+        init_theta = np.ascontiguousarray(init_thetas[k], dtype=np.float64)
+        cov = np.ascontiguousarray(proposal_covs[k], dtype=np.float64).reshape(n_params, n_params)
+        consts = np.ascontiguousarray(list(init_theta) + list(model_constants or ()), dtype=np.float64)
+        pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM["BPF"], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
+                           _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, ptr(consts), int(consts.size),
+                           ptr(y), ptr(ot), int(seeds[k]), 0, None, None, None, 0, 0)
+        cfgs.append(_lib.PmmhConfig(pf, int(m), int(n_params), ptr(init_theta), ptr(cov), ptr(tr), ptr(pk), ptr(pa),
+                                    ptr(pb), int(seeds[k]), int(chain_indices[k]), 1 if return_latent_state_est else 0))
+        theta_chain = np.zeros((m, n_params))
+        ll_chain = np.zeros(m)
+        se_chain = np.zeros((m, T + 1)) if return_latent_state_est else None
+        acc = np.zeros(1, dtype=np.int32)
+        ms = np.zeros(1)
+        ress.append(_lib.PmmhResult(ptr(theta_chain), ptr(ll_chain), ptr(se_chain), ptr(acc), ptr(ms)))
+        keep.append((init_theta, cov, consts))
+        outs.append({"theta_chain": theta_chain, "loglike_chain": ll_chain, "state_est_chain": se_chain, "_acc": acc, "_ms": ms})
+    carr = (_lib.PmmhConfig * K)(*cfgs)
+    rarr = (_lib.PmmhResult * K)(*ress)
+    _lib.check(_lib.load().bssm_pmmh_chains_batch(ctx.handle, K, C.cast(carr, C.c_void_p), C.cast(rarr, C.c_void_p)))
+    for o in outs:
+        o["accepted"] = int(o.pop("_acc")[0]); o["device_ms"] = float(o.pop("_ms")[0]); o["batched"] = True
+    return outs
 
 
 def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors, pilot_init_params, burn_in,
@@ -310,78 +361,121 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     pf_rf = kwargs.pop("pf_resample_fn", "stratified")
     tune_control = dict(tune_control)
 
-    def one_chain(c, ctx_c):
+    batch_chains = bool(kwargs.pop("batch_chains", True))     # lock-step chains in one launch per iteration when the filter fits
+    owner_consts = list(owner.constants) if owner is not None else []
+
+    def prepare(c, ctx_c):
+        """Step 1 of chain_result (R/pmmh.R:353-376): pilot chain -> start, proposal covariance, particle count."""
         init_theta = [float(pilot_init_params[c][k]) for k in prior_names]
         if verbose:
             print("Running chain %d..." % (c + 1))
         chain_n, chain_cov = num_particles, proposal_cov
         pilot = None
         if use_pilot:
-            # Step 1 of chain_result (R/pmmh.R:353-376): pilot chain -> start, proposal covariance, particle count
             if verbose:
                 print("Running pilot chain for tuning...")
             algorithm = "APF" if pf_wrapper is auxiliary_filter else "BPF"
-            owner_c = getattr(init_fn, "owner", None)
-            consts = list(owner_c.constants) if owner_c is not None else []
-            from .filters import particle_filter_core
+            from .filters import bootstrap_filter_batch, particle_filter_core
+            p_ra, p_rf = tune_control["pilot_resample_algorithm"], tune_control["pilot_resample_fn"]
+            small = batch_chains and batch_eligible(pf_wrapper, model, tune_control["pilot_n"], p_rf)
+
+            def pf_ll_batch(theta, n, tags, _c=c):
+                # the repeated runs of .pilot_run in ONE launch (same values as pf_ll one at a time)
+                th = np.tile(np.asarray(list(theta) + owner_consts, dtype=np.float64), (len(tags), 1))
+                r = bootstrap_filter_batch(y, int(n), init_fn, transition_fn, log_likelihood_fn, th, int(seeds[_c]),
+                                           [(1 << 40) + int(t) for t in tags], obs_times=obs_times,
+                                           resample_algorithm=p_ra, resample_fn=p_rf, ctx=ctx_c)
+                if np.any(r["status"] != 0):
+                    raise ValueError(_lib.load().bssm_status_string(int(r["status"][r["status"] != 0][0])).decode())
+                return r["loglike"]
 
             def pf_ll(theta, n, tag, _c=c):
-                r = particle_filter_core(y, int(n), model, list(theta) + consts, algorithm, obs_times,
-                                         tune_control["pilot_resample_algorithm"], tune_control["pilot_resample_fn"],
+                if small:                      # a small filter: the one-launch kernel, also for a single run
+                    return float(pf_ll_batch(theta, n, [tag])[0])
+                r = particle_filter_core(y, int(n), model, list(theta) + owner_consts, algorithm, obs_times, p_ra, p_rf,
                                          None, False, seed=int(seeds[_c]), stream=(1 << 40) + int(tag), ctx=ctx_c)
                 return r["loglike"]
 
             pilot = run_pilot_chain(pf_ll, tune_control["pilot_m"], tune_control["pilot_n"], tune_control["pilot_reps"],
                                     priors, tune_control["pilot_proposal_sd"], transform, init_theta,
                                     np.random.default_rng([int(seeds[c]), 77]), verbose,
-                                    message=(print if verbose else (lambda *_: None)))
+                                    message=(print if verbose else (lambda *_: None)),
+                                    pf_batch=pf_ll_batch if small else None)
             init_theta = [float(v) for v in pilot["pilot_theta_mean"]]
             chain_cov = pilot["pilot_theta_cov"] if proposal_cov is None else proposal_cov
             chain_n = pilot["target_n"] if num_particles is None else num_particles
+        return {"init_theta": init_theta, "cov": chain_cov, "n": int(chain_n), "pilot": pilot}
+
+    def main_chain(c, prep, ctx_c):
         runner = _chain_runner or run_chain_device
-        kw = dict(pf_wrapper=pf_wrapper, y=y, m=m, model=model, n_params=n_params, init_theta=init_theta,
-                  proposal_cov=chain_cov, transform=transform, priors=priors, num_particles=chain_n,
+        kw = dict(pf_wrapper=pf_wrapper, y=y, m=m, model=model, n_params=n_params, init_theta=prep["init_theta"],
+                  proposal_cov=prep["cov"], transform=transform, priors=priors, num_particles=prep["n"],
                   seed=int(seeds[c]), chain_index=c, obs_times=obs_times, resample_algorithm=pf_ra,
                   resample_fn=pf_rf, return_latent_state_est=return_latent_state_est,
                   model_constants=(owner.constants if owner is not None else None))
         if ctx_c is not None:
             kw["ctx"] = ctx_c
-        r = runner(**kw)
-        if pilot is not None:
-            r["pilot"] = pilot
-        return r
+        return runner(**kw)
 
-    # Chains of one rank are independent (R/pmmh.R:511-531): with several chains on this GPU, run up to
-    # `chains_per_gpu` of them at once, each on its own context (= HIP stream); a single filter leaves most of the
-    # chip idle between its dependent launches, two or three concurrent chains fill it.
+    # Chains of one rank are independent (R/pmmh.R:511-531).  Small filters (N <= 2048, the reference's native range):
+    # all of this rank's chains advance in lock-step, one kernel launch per iteration with one workgroup per chain.
+    # Larger filters: up to `chains_per_gpu` chains at once, each on its own context (= HIP stream); a single big
+    # filter leaves most of the chip idle between its dependent launches, two or three concurrent chains fill it.
     conc = int(kwargs.pop("chains_per_gpu", 2 if _chain_runner is None else 1))
     conc = max(1, min(conc, len(mine)))
+    ctxs = []
     if conc > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        dim_c = models.dim_of(model)
         cap = int(num_particles) if num_particles is not None else 1024
+        ctxs = [_lib.Context(_lib.default_context(1).device, max(cap, 1024), models.dim_of(model)) for _ in range(conc)]
+
+    def run_pool(fn, items):
+        """fn(item, ctx) over items, `conc` at a time, each worker holding one context."""
+        if conc <= 1 or len(items) <= 1:
+            return {it: fn(it, ctxs[0] if ctxs else None) for it in items}
         import queue
-        ctxs = [_lib.Context(_lib.default_context(1).device, max(cap, 1024), dim_c) for _ in range(conc)]
+        from concurrent.futures import ThreadPoolExecutor
         free = queue.Queue()
         for cx in ctxs:
             free.put(cx)
 
-        def task(c):
+        def task(it):
             cx = free.get()                 # a context serves one chain at a time
             try:
-                return one_chain(c, cx)
+                return fn(it, cx)
             finally:
                 free.put(cx)
 
-        try:
-            with ThreadPoolExecutor(conc) as ex:
-                futs = {c: ex.submit(task, c) for c in mine}
-                results = {c: futs[c].result() for c in mine}
-        finally:
-            for cx in ctxs:
-                cx.close()
-    else:
-        results = {c: one_chain(c, None) for c in mine}
+        with ThreadPoolExecutor(conc) as ex:
+            futs = {it: ex.submit(task, it) for it in items}
+            return {it: futs[it].result() for it in items}
+
+    try:
+        preps = run_pool(prepare, list(mine))
+        results = {}
+        groups = {}
+        for c in mine:
+            ok = batch_chains and _chain_runner is None and batch_eligible(pf_wrapper, model, preps[c]["n"], pf_rf)
+            groups.setdefault(preps[c]["n"] if ok else None, []).append(c)
+        for n_g, cs in groups.items():
+            if n_g is None:
+                continue
+            outs = run_chains_batch_device(
+                pf_wrapper=pf_wrapper, y=y, m=m, model=model, n_params=n_params,
+                init_thetas=[preps[c]["init_theta"] for c in cs], proposal_covs=[preps[c]["cov"] for c in cs],
+                transform=transform, priors=priors, num_particles=n_g, seeds=[int(seeds[c]) for c in cs],
+                chain_indices=cs, obs_times=obs_times, resample_algorithm=pf_ra, resample_fn=pf_rf,
+                return_latent_state_est=return_latent_state_est, ctx=(ctxs[0] if ctxs else None),
+                model_constants=(owner.constants if owner is not None else None))
+            for c, o in zip(cs, outs):
+                results[c] = o
+        rest = groups.get(None, [])
+        results.update(run_pool(lambda c, cx: main_chain(c, preps[c], cx), rest))
+        for c in mine:
+            if preps[c]["pilot"] is not None:
+                results[c]["pilot"] = preps[c]["pilot"]
+    finally:
+        for cx in ctxs:
+            cx.close()
     for c in mine:
         local[c] = results[c]["theta_chain"]
         extras[c] = results[c]

@@ -229,6 +229,12 @@ typedef struct {
 
 int bssm_pmmh_chain(bssm_ctx* ctx, const bssm_pmmh_config* cfg, bssm_pmmh_result* res);
 
+/* n_chains chains advancing in lock-step over bssm_pf_run_batch: iteration i of every chain is ONE kernel launch (one
+ * workgroup per chain).  The chains must share data, filter settings and m, and meet bssm_pf_run_batch's limits
+ * (N <= 2048, BPF, scalar models, stratified / systematic).  ress[k] is exactly what bssm_pmmh_chain returns for
+ * cfgs[k]; device_ms reports the total device time divided by n_chains. */
+int bssm_pmmh_chains_batch(bssm_ctx* ctx, int n_chains, const bssm_pmmh_config* cfgs, bssm_pmmh_result* ress);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,3 +99,58 @@ def test_batch_many_filters_and_limits():
     assert b.batch_max_particles() == 2048
     with pytest.raises(Exception):
         b.bootstrap_filter_batch(y, 2049, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas[:2], 1)
+
+
+def _pmmh_kw(b, ys, **over):
+    m = b.models.linear_gaussian()
+    kw = dict(pf_wrapper=b.bootstrap_filter, y=ys, m=50, init_fn=m.init_fn, transition_fn=m.transition_fn,
+              log_likelihood_fn=m.log_likelihood_fn,
+              log_priors={"phi": b.prior_normal(0, 1), "sigma_x": b.prior_exponential(1), "sigma_y": b.prior_exponential(1)},
+              pilot_init_params=[{"phi": 0.5 + 0.1 * c, "sigma_x": 1.0, "sigma_y": 1.0} for c in range(4)],
+              burn_in=10, num_chains=4, seed=99, param_transform={"phi": "identity", "sigma_x": "log", "sigma_y": "log"})
+    kw.update(over)
+    return kw
+
+
+def test_pmmh_lockstep_chains_match_per_chain():
+    """bssm_pmmh_chains_batch (all chains of the rank, one launch per iteration) against bssm_pmmh_chain one chain at
+    a time: identical chains, log-likelihoods and latent state estimates (placement independence,
+    tests/testthat/test-pmmh.R:499-503)."""
+    import warnings
+    import bayesssm_amd as b
+    ys = _data(30)
+    kw = _pmmh_kw(b, ys, num_particles=500, proposal_cov=np.eye(3) * 0.02, return_latent_state_est=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = b.pmmh(batch_chains=False, chains_per_gpu=1, **kw)
+        c = b.pmmh(batch_chains=True, **kw)
+    for k in ("chain", "phi", "sigma_x", "sigma_y"):
+        assert (a["theta_chain"][k] == c["theta_chain"][k]).all()
+    for ch in range(4):
+        ea, ec = a["_extras"]["local_chains"][ch], c["_extras"]["local_chains"][ch]
+        assert ec.get("batched") and not ea.get("batched")
+        np.testing.assert_array_equal(ea["loglike_chain"], ec["loglike_chain"])
+        np.testing.assert_array_equal(ea["state_est_chain"], ec["state_est_chain"])
+        assert ea["accepted"] == ec["accepted"] and 0 < ec["accepted"] < 50
+
+
+def test_pmmh_pilot_batched_matches_unbatched():
+    """The pilot (R/pmmh_tuning.R:111-317) through the one-launch kernel -- its MH filter runs with F = 1, the
+    pilot_reps repetitions as one batch -- gives the pilot mean / covariance / target_n of the multi-launch path."""
+    import warnings
+    import bayesssm_amd as b
+    ys = _data(20)
+    tc = b.default_tune_control(pilot_m=300, pilot_burn_in=10, pilot_reps=12, pilot_n=64, pilot_proposal_sd=0.15)
+    kw = _pmmh_kw(b, ys, m=30, num_chains=2, pilot_init_params=[{"phi": 0.7, "sigma_x": 1.0, "sigma_y": 0.8}] * 2,
+                  tune_control=tc, burn_in=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = b.pmmh(batch_chains=False, chains_per_gpu=1, **kw)
+        c = b.pmmh(batch_chains=True, **kw)
+    for ch in range(2):
+        pa, pc = a["_extras"]["local_chains"][ch]["pilot"], c["_extras"]["local_chains"][ch]["pilot"]
+        np.testing.assert_array_equal(pa["pilot_theta_chain"], pc["pilot_theta_chain"])
+        np.testing.assert_array_equal(pa["pilot_theta_cov"], pc["pilot_theta_cov"])
+        assert pa["target_n"] == pc["target_n"] and pa["variance_estimate"] == pc["variance_estimate"]
+    for k in ("phi", "sigma_x", "sigma_y"):
+        assert (a["theta_chain"][k] == c["theta_chain"][k]).all()
