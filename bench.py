@@ -55,7 +55,7 @@ def cpu_baseline(ys, theta, rank):
     rnorm inside its timed path, so this flatters the CPU)."""
     from oracle import oracle as orc
     orc.build()
-    Ns, Ts = 1 << 18, 200
+    Ns, Ts = 1 << 19, min(len(ys), 1000)          # ~10 s of single-core work at ~50 M particle-steps/s
     rng = np.random.default_rng(7)
     zi = rng.standard_normal(Ns)
     zt = rng.standard_normal((Ts, Ns))
@@ -65,7 +65,7 @@ def cpu_baseline(ys, theta, rank):
     dt = time.perf_counter() - t0
     return {"value": Ns * Ts / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
             "sample": "oracle/bssm_oracle.c (C restatement of R/particle_filter_core.R + src/resampling.cpp), "
-                      "same model, N=2^18, T=200, SISR+systematic, draws pre-generated (not timed), %.1f s" % dt,
+                      "same model, N=2^19 (half of C2's particles), T=%d, SISR+systematic, draws pre-generated (not timed), %.1f s" % (Ts, dt),
             "host_cpus": os.cpu_count()}
 
 
@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-pmmh", action="store_true")
+    ap.add_argument("--no-batch", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,7 +169,7 @@ def main():
             nbytes = KERNEL_BYTES.get(dom, 0.0) * N
             ach = nbytes / (kern[dom]["avg_us"] * 1e-6) / 1e9 if nbytes else 0.0
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
             if N == 1 << 20 and os.path.exists(tpath):
                 # fabric-side bytes per launch of this kernel, from committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
                 # see the file's "source"); not collected live
@@ -196,6 +197,24 @@ def main():
             out["pmmh"] = {"iters_per_sec_per_gpu": (iters + 1) / dt1, "iterations_timed": iters + 1,
                            "accepted": ch["accepted"], "note": "1 chain on this GPU; chains shard one per GPU "
                            "(no data-path collective), so N GPUs run N chains at this rate each"}
+        if not args.no_batch:
+            # the reference's native regime (N <= 1000 inside PMMH, R/pmmh_tuning.R:55-57): many small filters per launch,
+            # one workgroup each (bssm_pf_run_batch); and chains advancing in lock-step over it.  Reported alongside.
+            Fb, Nb = 512, 1000
+            thb = np.tile(theta, (Fb, 1))
+            bkw = dict(resample_algorithm="SISAR", resample_fn="stratified", ctx=ctx)
+            b.bootstrap_filter_batch(ys, Nb, m.init_fn, m.transition_fn, m.log_likelihood_fn, thb[:2], 1, **bkw)
+            t2 = time.perf_counter()
+            ob = b.bootstrap_filter_batch(ys, Nb, m.init_fn, m.transition_fn, m.log_likelihood_fn, thb, 1405, **bkw)
+            dt2 = time.perf_counter() - t2
+            t3 = time.perf_counter()
+            b.bootstrap_filter(ys, Nb, m.init_fn, m.transition_fn, m.log_likelihood_fn, return_particles=False, seed=1405,
+                               stream=0, phi=theta[0], sigma_x=theta[1], sigma_y=theta[2], **bkw)
+            dt3 = time.perf_counter() - t3
+            out["small_filters"] = {
+                "workload": "%d independent bootstrap filters, N=%d, T=%d, SISAR + stratified, one kernel launch" % (Fb, Nb, T),
+                "particle_steps_per_s": Fb * Nb * T / dt2, "filters_per_s": Fb / dt2, "device_ms": ob["device_ms"],
+                "one_at_a_time_filters_per_s": 1.0 / dt3, "speedup_vs_one_at_a_time": dt3 / (dt2 / Fb)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ys, theta, rank)
     if dist is not None:
