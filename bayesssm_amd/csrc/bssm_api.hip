@@ -645,6 +645,8 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
 
 // ---- many small filters per launch (one workgroup = one whole filter) -------------------------
 extern "C" int bssm_pf_batch_max_particles(void) { return EB; }
+static int g_batch_lit_max = 384;       // tuning knob (dev/test): largest N that takes the in-order exact sums in k_pf_batch
+extern "C" void bssm_debug_set_batch_literal_max(int n) { g_batch_lit_max = n; }
 
 extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_filters, const double* thetas,
                                  const unsigned long long* seeds, const unsigned long long* streams, bssm_pf_batch_result* res)
@@ -705,10 +707,14 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     BatchArgs g;
     g.N = (int)N; g.T = T; g.resample_algorithm = cfg->resample_algorithm; g.resample_fn = cfg->resample_fn;
     g.lim = g_debug_lim > 0 ? g_debug_lim : rec_window(N);
+    g.lit_max = g_batch_lit_max;
     g.threshold = threshold; g.y = (const double*)d_y; g.obs_times = (const int*)d_ot;
     g.theta = (const double*)d_th; g.theta_stride = nth; g.log_sy = (const double*)d_lsy; g.keys = (const PhiloxKey*)d_keys;
     g.loglike = (double*)d_ll; g.state_est = (double*)d_se; g.ess = (double*)d_ess; g.llh = (double*)d_llh;
     g.dead = (int*)d_dead; g.flags = (uint32_t*)d_flags; g.res_calls = (int*)d_res;
+    g.phase_cycles = nullptr;
+    void* d_ph = nullptr;
+    if (g_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 64, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 64, c->stream)); g.phase_cycles = (long long*)d_ph; }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_pf_batch", k_pf_batch<0>, F, NT, 0, g);
     else LAUNCH(c, "k_pf_batch", k_pf_batch<1>, F, NT, 0, g);
@@ -725,6 +731,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (res->loglike_history && T > 0) HIPCHK(hipMemcpyAsync(res->loglike_history, d_llh, (size_t)F * T * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
+    if (d_ph) { long long h[8]; HIPCHK(hipMemcpy(h, d_ph, 64, hipMemcpyDeviceToHost)); fprintf(stderr, "k_pf_batch filter 0 cycles/observation: step %lld, weights+scan<W> %lld, apply %lld, carry/store %lld\n", h[0] / std::max(T, 1), h[1] / std::max(T, 1), h[2] / std::max(T, 1), h[3] / std::max(T, 1)); }
     if (res->device_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *res->device_ms = ms; }
     int first_bad = BSSM_OK;
     for (int f = 0; f < F; f++) {

@@ -870,6 +870,41 @@ __device__ __forceinline__ void block_literal(uint64_t* tin /* LDS [NT] */, uint
     __syncthreads();
 }
 
+// One block, few terms (the batched small filters): thread 0 adds the terms in order from exact +0 -- the reference's own
+// loop (src/resampling.cpp:20,25) -- and records every lane's incoming state.  For a few hundred terms this is faster
+// than the parallel record machinery, whose fixed latency (scan + boundary chain) is ~13k cycles per pass.
+// `terms`: the n terms in order (LDS), already published and synchronised by the caller.
+static_assert(EL == 8, "block_literal_terms unrolls 8 terms per lane");
+__device__ __forceinline__ void block_literal_terms(uint64_t* tin /* LDS [NT] */, const double* terms, int n)
+{
+    const int t = threadIdx.x;
+    const int nl = (n + EL - 1) / EL;                      // lanes that hold terms (terms[] is zero-padded to a multiple of EL by the caller)
+    if (t == 0) {
+        double c = 0.0;
+        // two lanes (16 terms) per trip, the next trip's terms loaded a whole trip ahead: the LDS latency (~130 cycles)
+        // hides under 16 dependent adds.  Reading one lane past the last is harmless (inside the EB-sized buffer; the
+        // values are added only when tt + 1 < nl).
+        const double2* p = reinterpret_cast<const double2*>(terms);
+        double2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6], a7 = p[7];
+        for (int tt = 0; tt < nl; tt += 2) {
+            const int nx = (tt + 2 < nl) ? tt + 2 : tt;
+            const double2* q = p + (EL / 2) * nx;
+            const double2 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3], b4 = q[4], b5 = q[5], b6 = q[6], b7 = q[7];
+            tin[tt] = d2b(c);
+            c = c + a0.x; c = c + a0.y; c = c + a1.x; c = c + a1.y; c = c + a2.x; c = c + a2.y; c = c + a3.x; c = c + a3.y;
+            if (tt + 1 < nl) {
+                tin[tt + 1] = d2b(c);
+                c = c + a4.x; c = c + a4.y; c = c + a5.x; c = c + a5.y; c = c + a6.x; c = c + a6.y; c = c + a7.x; c = c + a7.y;
+            }
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+        }
+        tin[NT] = d2b(c);                                   // the block's outgoing state
+    }
+    __syncthreads();
+    if (t >= nl) tin[t] = tin[NT];                          // lanes past the end: nothing left to add
+    __syncthreads();
+}
+
 // block-wide min and max of two int64 pairs (segments 0 and 1), lanes opt in per segment
 __device__ __forceinline__ void block_minmax2(SegSmem& sm, long long mn[2], long long mx[2])
 {
@@ -920,8 +955,8 @@ struct FromLw {
 
 // The body of k_local for workgroup `bidx` of `nblk`; shared storage is handed in so that the batched small-filter kernel
 // (k_pf_batch: one workgroup runs a whole filter, nblk == 1) executes exactly this code.  MAXBL: capacity of the partials.
-template <int MODE, bool FROM_LW, int MAXBL>
-__device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin, double* es /* [MAXBL], FROM_LW only */, const int bidx, const int nblk,
+template <int MODE, bool FROM_LW, int MAXBL, bool LIT = false>
+__device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, double* es /* [MAXBL], FROM_LW only */, const int bidx, const int nblk,
                                             const double* __restrict__ w, long long nw, const double* __restrict__ ain,
                                             int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
                                             const FromLw& f)
@@ -963,10 +998,13 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin, double* 
             const bool in = i < f.nb;
             pmv[k] = in ? f.pm[i] : -INFINITY; psv[k] = in ? f.ps[i] : 0.0; pqv[k] = in ? f.pq[i] : 0.0;
         }
+        // one block (nb == 1, finite max): M = pm[0], S = ps[0] exp(0) = ps[0], sq = pq[0] -- exactly what the reductions below
+        // return (they add zeros / take max with -inf), without their latency
+        const bool one = (MAXBL == NT) && (f.nb == 1) && (f.pm[0] > -INFINITY);
         double m = -INFINITY;
 #pragma unroll
         for (int k = 0; k < MAXBL / NT; k++) m = fmax(m, pmv[k]);
-        const double M = block_max(m, sm.sh4);
+        const double M = one ? f.pm[0] : block_max(m, sm.sh4);
         const bool degenerate = (f.plan == PLAN_PF) && (M < -1e8);       // all(log_weights < -1e8)  (:189-202)
         if (degenerate) {
             if (bidx == 0 && t == 0) {
@@ -982,8 +1020,9 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin, double* 
             if (pmv[k] > -INFINITY) { const double ex = exp(pmv[k] - M); x = psv[k] * ex; sq += pqv[k] * ex * ex; }
             es[i] = x; se += x;
         }
-        const double S = block_sum(se, sm.sh4);              // (block_sum syncs: es[] is complete)
-        sq = block_sum(sq, sm.sh4);
+        double S;
+        if (one) { S = f.ps[0] * exp(f.pm[0] - M); sq = f.pq[0] * exp(f.pm[0] - M) * exp(f.pm[0] - M); __syncthreads(); }
+        else { S = block_sum(se, sm.sh4); sq = block_sum(sq, sm.sh4); }     // (block_sum syncs: es[] is complete)
         int doit = 1;
         if (f.plan == PLAN_PF) {
             const double ess = 1.0 / (sq / (S * S));                                          // :211
@@ -1001,7 +1040,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin, double* 
         double ts0 = 0.0;
 #pragma unroll
         for (int k = 0; k < MAXBL / NT; k++) ts0 += es[t * (MAXBL / NT) + k];
-        double pre = block_excl_scan(ts0, sm.sh4);
+        double pre = one ? 0.0 : block_excl_scan(ts0, sm.sh4);
         if (t == bidx / (MAXBL / NT)) {           // the one lane whose slice holds this block: one division
             double pp = pre;
             for (int k = 0; k < bidx % (MAXBL / NT); k++) pp += es[t * (MAXBL / NT) + k];
@@ -1025,7 +1064,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin, double* 
             const double x = (j0 + k < nw) ? exp(l8[k] - M) / S : 0.0;                         // :205-207
             v[k] = x; s1 += x;
         }
-        if (j0 + EL <= nw) {
+        if (j0 + EL <= nw || (LIT && j0 < nw)) {             // (LIT: the partly filled lane stores its zero padding too -- the in-order pass reads whole lanes)
             double2* p2 = reinterpret_cast<double2*>(f.w_out + j0);
 #pragma unroll
             for (int k = 0; k < EL / 2; k++) { double2 q2; q2.x = v[2 * k]; q2.y = v[2 * k + 1]; p2[k] = q2; }
@@ -1046,6 +1085,13 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin, double* 
         a_in = a_in_pre;
     }
     BSSM_STAMP(st, dbg, 2, 1, stamper && v[0] >= 0.0);
+    if (LIT) {
+        // one block of few terms, incoming state +0 (FROM_LW: the terms are already in f.w_out, in order, zero beyond nw)
+        __syncthreads();
+        block_literal_terms(tin, FROM_LW ? f.w_out : w, (int)nw);
+        if (t == NT - 1) { BlockRec br; br.prefix = rec_abs(tin[NT]); br.tail_from = NT; br.nside = 0; brec[bidx] = br; }
+        return;
+    }
     BlockScan bs;
     block_scan<MODE>(sm, v, a_in, lim, bs);
     __syncthreads();
@@ -1431,8 +1477,8 @@ struct ApplyArgs {
     double* se_part;              // [B][dim] partial sums of x * (1/N) after resampling, or nullptr
 };
 
-template <int KIND>
-__device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
+template <int KIND, bool LIT = false>
+__device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
                                             const ApplyArgs& a, DevState* st)
 {
     const int t = threadIdx.x;
@@ -1471,13 +1517,23 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin, int* Tl 
 #pragma unroll
     for (int k = 0; k < EL; k++) v[k] = v[k] / total;                  // prob = weights / total (src/resampling.cpp:24,51)
     BSSM_STAMP(st, dbg, 3, 1, stamper && v[0] >= 0.0);
-    BlockScan bs;
-    block_scan<MODE_P>(sm, v, a_in_p, a.lim, bs);
-    __syncthreads();
-    BSSM_STAMP(st, dbg, 3, 2, stamper);
     uint64_t ent;
-    const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
-    if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
+    if (LIT) {
+        // one block of few terms from exact +0: publish prob (zero beyond nw) in the not yet written destination buffer and add in order
+        double2* p2 = reinterpret_cast<double2*>(a.xdst + (long long)t * EL);
+#pragma unroll
+        for (int k = 0; k < EL / 2; k++) { double2 q2; q2.x = v[2 * k]; q2.y = v[2 * k + 1]; p2[k] = q2; }
+        __syncthreads();
+        block_literal_terms(tin, a.xdst, (int)a.nw);
+        ent = tin[t];
+    } else {
+        BlockScan bs;
+        block_scan<MODE_P>(sm, v, a_in_p, a.lim, bs);
+        __syncthreads();
+        BSSM_STAMP(st, dbg, 3, 2, stamper);
+        const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
+        if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
+    }
     BSSM_STAMP(st, dbg, 3, 3, stamper);
     // the reference chain itself, from the exact incoming state
     int Tk[EL];
@@ -1742,6 +1798,7 @@ __global__ void k_dump_uniforms(PhiloxKey key, uint32_t call, long long n, doubl
 // ---------------------------------------------------------------------------
 struct BatchArgs {
     int N, T, resample_algorithm, resample_fn, lim;
+    int lit_max;                                      // N <= lit_max: exact sums by the in-order pass (block_literal_terms)
     double threshold;
     const double* y; const int* obs_times;            // [T]; obs_times may be nullptr (1..T)
     const double* theta; int theta_stride;            // [F][theta_stride]: phi, sigma_x, sigma_y
@@ -1749,6 +1806,7 @@ struct BatchArgs {
     const PhiloxKey* keys;                            // [F]
     double* loglike; double* state_est; double* ess; double* llh;    // [F], [F][T+1], [F][T+1], [F][T]
     int* dead; uint32_t* flags; int* res_calls;       // [F]
+    long long* phase_cycles;                          // dev tool: [8] cycles per phase summed over filter 0's observations, or nullptr
 };
 
 // k_step<MODEL, TRANS, WEIGHT, false> for one block of up to EB particles, by NT threads: thread t plays the threads
@@ -1760,6 +1818,8 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
     constexpr int R = NTS / NT;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double l0[R], l1[R];
+    // rounds past the last particle contribute max = -inf and sums = 0 in the k_step they re-enact: skip their work
+    const int rmax = (int)((N + 2 * NT - 1) / (2 * NT));
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const long long j = 2 * (long long)(t + NT * r);
@@ -1785,7 +1845,7 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
     if (WEIGHT) {
         double v[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) v[r] = wave_max(fmax(l0[r], l1[r]));
+        for (int r = 0; r < R; r++) v[r] = (r < rmax) ? wave_max(fmax(l0[r], l1[r])) : -INFINITY;
         __syncthreads();
         if (lane == 0) {
 #pragma unroll
@@ -1803,7 +1863,7 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
                 if (l0[r] > -INFINITY) { const double e = exp(l0[r] - bm); s_ += e; q_ += e * e; }
                 if (l1[r] > -INFINITY) { const double e = exp(l1[r] - bm); s_ += e; q_ += e * e; }
             }
-            sv[r] = wave_sum(s_); qv[r] = wave_sum(q_);
+            if (r < rmax) { sv[r] = wave_sum(s_); qv[r] = wave_sum(q_); } else { sv[r] = 0.0; qv[r] = 0.0; }
         }
         __syncthreads();
         if (lane == 0) {
@@ -1831,7 +1891,7 @@ template <int MODEL>
 __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
 {
     __shared__ SegSmem sm;
-    __shared__ uint64_t tin[NT];
+    __shared__ uint64_t tin[NT + 1];
     __shared__ int Tl[EB];
     __shared__ int Tbegin;
     __shared__ double es[NT];
@@ -1853,6 +1913,7 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
         par.n_total = 0.0; par.s0 = 0.0; par.i0 = 0.0; par.lgy = 0.0;
     }
     const PhiloxKey key = g.keys[fi];
+    const bool lit = g.N <= g.lit_max;      // few terms: the in-order pass beats the record machinery's fixed latency
     if (t == 0) {
         st.loglike = 0.0; st.lse_max = 0.0; st.lse_sum = 0.0; st.ess = 0.0; st.total_bits = 0;
         st.do_resample = 0; st.dead = 0; st.flags = 0; st.res_calls = 0; st.cur_call = 0; st.debug_stop = 0;
@@ -1867,12 +1928,16 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
     __syncthreads();
     if (t == 0 && g.state_est) { double s0 = 0.0; s0 += sep; g.state_est[(long long)fi * (T + 1)] = s0; }
     double* xa = XA; double* xb = XB;
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+    const bool prof = (g.phase_cycles != nullptr) && fi == 0 && t == 0;
+#define PH(k) { if (prof) { const long long c_ = clock64(); ph[k] += c_ - pc; pc = c_; } }
     int ktrans = 0, prev_t = 0;
     for (int i = 1; i <= T; i++) {                                                        // :123
         const int ot = g.obs_times ? g.obs_times[i - 1] : i;
         const int gap = ot - prev_t;                                                      // :124
         prev_t = ot;
         const double yi = g.y[i - 1];
+        long long pc = prof ? clock64() : 0;
         NoiseSrc ns; ns.arr = nullptr; ns.key = key; ns.purpose = DRAW_TRANS;
         for (int step = 1; step <= gap; step++) {                                         // :125-136
             ns.call = (uint32_t)ktrans;
@@ -1886,14 +1951,17 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
             step_emul<MODEL, false, 1>(sh16, xa, LW, N, par, yi, ns, &pm1, &ps1, &pq1);
             __syncthreads();
         }
+        PH(0)
         if (t == 0) sep = 0.0;
         FromLw fl;
         fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.ain_out = &ainw1;
         fl.plan = PLAN_PF; fl.N = N; fl.obs_i = i; fl.resample_algorithm = g.resample_algorithm; fl.threshold = g.threshold;
         fl.ess_out = g.ess + (long long)fi * (T + 1); fl.llh_out = g.llh + (long long)fi * T; fl.resampled_out = nullptr;
         // normalise + loglik/ESS/decision + the exact sum(weights) of the block (:204-218, src/resampling.cpp:20-24)
-        local_block<MODE_W, true, NT>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fl);
+        if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fl);
+        else local_block<MODE_W, true, NT, false>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fl);
         __syncthreads();
+        PH(1)
         if (t == 0 && !st.dead && !st.flags && st.do_resample) {      // what k_resolve<W> / k_resolve<P> come to for one block
             const uint64_t fs = br.prefix.o[0];
             const double tot = b2d(fs);
@@ -1907,9 +1975,13 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
         a.w = LW; a.nw = N; a.ain_p = &ainp1; a.cin = &cin1; a.lim = g.lim; a.n = (int)N;
         a.u_base = nullptr; a.u_stride = 0; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;
         a.xsrc = xa; a.xdst = xb; a.dim = 1; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = &sep;
-        if (g.resample_fn == 1) apply_block<1>(sm, tin, Tl, Tbegin, 0, 1, a, &st);       // systematic
-        else apply_block<0>(sm, tin, Tl, Tbegin, 0, 1, a, &st);                           // stratified
+        if (g.resample_fn == 1) {                                                         // systematic
+            if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
+        } else {                                                                          // stratified
+            if (lit) apply_block<0, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<0, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
+        }
         __syncthreads();
+        PH(2)
         if (g.resample_algorithm != 1) {                 // SIS / SISAR: carry over when no resample ran (:238)
             carry_block(sm.sh4, 0, xa, xb, LW, N, 1, &sep, &st);
             __syncthreads();
@@ -1918,7 +1990,10 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
         if (t == 0 && g.state_est) { double s0 = 0.0; s0 += sep; g.state_est[(long long)fi * (T + 1) + i] = s0; }   // :237-241
         if (st.dead) break;                              // degenerate weights: the reference returns at once (:189-202)
         __syncthreads();
+        PH(3)
     }
+    if (prof) { for (int k = 0; k < 6; k++) g.phase_cycles[k] = ph[k]; }
+#undef PH
     if (t == 0) { g.loglike[fi] = st.loglike; g.dead[fi] = st.dead; g.flags[fi] = st.flags; g.res_calls[fi] = st.res_calls; }
 }
 

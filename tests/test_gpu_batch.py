@@ -46,6 +46,28 @@ def test_batch_matches_single_bitwise(model, N, ra, rf):
         assert out["n_res_calls"][k] == ref["_extras"]["n_res_calls"]
 
 
+def test_batch_in_order_and_record_paths_agree():
+    """k_pf_batch takes the in-order exact sums for small N and the record machinery above a threshold; both are exact,
+    so moving the threshold must not change a single bit."""
+    import bayesssm_amd as b
+    from bayesssm_amd import _lib
+    m = b.models.ar1_sin()
+    y = _data(15)
+    thetas = np.array([[0.8, 1.0, 0.7], [0.4, 1.3, 0.5], [0.9, 0.6, 1.0]])
+    outs = []
+    try:
+        for lim in (0, 100000):
+            _lib.load().bssm_debug_set_batch_literal_max(lim)
+            outs.append([b.bootstrap_filter_batch(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 3,
+                                                  resample_algorithm="SISR", resample_fn=rf)
+                         for N in (5, 64, 333, 1500, 2048) for rf in ("systematic", "stratified")])
+    finally:
+        _lib.load().bssm_debug_set_batch_literal_max(384)
+    for a, c in zip(*outs):
+        for k in ("loglike", "state_est", "ess", "loglike_history"):
+            np.testing.assert_array_equal(a[k], c[k])
+
+
 def test_batch_obs_times_gaps_and_threshold():
     import bayesssm_amd as b
     m = b.models.linear_gaussian()
