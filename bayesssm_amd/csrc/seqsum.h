@@ -84,15 +84,18 @@ BSSM_HD bool near_pow2(uint64_t b, uint64_t near)
     return ef <= 1 || ef >= 0x7FE || mant <= near || mant >= (1ull << 52) - near;
 }
 
-// Ulp window half-width used for hypotheses over n terms.  Typical distance
-// between an approximate (tree) prefix and the sequential prefix is a few
-// sqrt(n) ulps; the window only affects speed (see header), not correctness.
+// Ulp window half-width used for hypotheses over n terms; the window only
+// affects speed (see header), not correctness.
 BSSM_HD int32_t rec_window(long long n)
 {
-    // 64*sqrt(n)+256, integer sqrt by bit tricks (n <= 2^40)
-    long long r = 0, bit = 1ll << 20;
-    while (bit) { if ((r + bit) * (r + bit) <= n) r += bit; bit >>= 1; }
-    long long w = 64 * r + 256;
+    // n + 1024 ulps.  Every add of the sequential sum is off by at most half an ulp of the final magnitude, so the
+    // sequential prefix lies within n/2 ulps of the true one and the approximate (tree / log-sum-exp) prefix within a
+    // few more: the window covers the WORST case.  Random weights only drift ~sqrt(n) ulps, but runs of EQUAL weights
+    // (integer-valued states, e.g. the SIR model: a few dozen distinct weights among 2^18 particles) round the same
+    // way add after add and drift linearly -- with a sqrt(n)-sized window those blocks all fell back to the in-order
+    // pass.  The price of a wide window is only that lanes within `window` ulps of a power of two are HARD
+    // (a 2^-30 sliver of the range at n = 2^22).
+    const long long w = n + 1024;
     return (int32_t)(w > (1ll << 28) ? (1ll << 28) : w);
 }
 

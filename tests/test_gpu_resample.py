@@ -169,3 +169,21 @@ def test_fallback_paths_stay_exact(B, ctx, oracle, lim):
             assert total_fallbacks > 0, "the tiny window did not exercise any fallback"
     finally:
         lib.bssm_debug_set_window(0)
+
+
+@pytest.mark.parametrize("n,distinct", [(1 << 18, 20), (1 << 20, 3), (300001, 1)])
+def test_runs_of_equal_weights_stay_on_the_fast_path(B, ctx, oracle, n, distinct):
+    """Integer-valued states (the SIR model) give a few dozen distinct weights among 2^18 particles.  Equal terms round the
+    same way add after add, so the sequential sum drifts LINEARLY from the tree sum the records are built around; the
+    window (seqsum.h rec_window) covers that worst case, so none of it may fall back to the in-order pass -- and the
+    result stays bit-exact."""
+    rng = np.random.default_rng(distinct)
+    vals = np.exp(rng.uniform(-30, 0, distinct))
+    w = vals[rng.integers(0, distinct, n)]
+    w[: n // 3] = np.sort(w[: n // 3])           # long runs of one value, then a random interleaving
+    U = rng.random()
+    got, cum, stats = B.resample_systematic_cpp(n, w, U=U, ctx=ctx, return_cum=True, return_stats=True)
+    want, wcum = oracle.resample_systematic(n, w, U, return_cum=True)
+    assert cum.tobytes() == wcum.tobytes()
+    assert (got == want).all()
+    assert int(stats[1]) == 0 and int(stats[2]) <= 64 * 8, stats      # no serial walks; at most a few HARD leaves re-run (8 terms each)
