@@ -82,6 +82,30 @@ __global__ void k3(long long* out, const uint64_t* g, uint64_t* sink, int nlinks
     sink[t] = s;
 }
 
+
+// the chain while the other waves of a 1024-thread workgroup wait at the barrier (as in k_resolve)
+__global__ __launch_bounds__(1024) void k4(long long* out, const uint64_t* g, uint64_t* sink, int nlinks, int mode)
+{
+    __shared__ WalkFn wf[65];
+    __shared__ uint64_t sseq[65];
+    const int t = threadIdx.x;
+    StepFn f; f.K0 = 4; f.K1 = 9; f.K2 = 14; f.K3 = 19; f.sref = 0; f.wlo = -(1ll << 60); f.whi = 1ll << 60; f.sh = 0; f.mode = 0;
+    for (int j = t; j < 65; j += 1024) wf[j] = walkfn_from(f, true);
+    __syncthreads();
+    uint64_t s = g[t & 63] & 0xffff;
+    long long acc = 0;
+    for (int r = 0; r < 20; r++) {
+        if (mode == 0) {                 // wave 0 walks, the rest wait at the barrier
+            if (t < 64) { long long c0 = clock64(); walk_chain(wf, sseq, nlinks, s); acc += clock64() - c0; }
+        } else {                         // every wave walks (redundantly): nobody waits
+            long long c0 = clock64(); uint64_t s2 = s; walk_chain(wf, sseq, nlinks, s2); acc += clock64() - c0; s = s2;
+        }
+        __syncthreads();
+    }
+    if (t == 0) out[0] = acc / 20;
+    sink[t & 63] = s;
+}
+
 int main()
 {
     long long* out; double *g, *sink;
@@ -104,5 +128,12 @@ int main()
     hipDeviceSynchronize();
     hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost);
     printf("walk_chain, 10 links, first execution in a fresh kernel: %lld cycles; second execution: %lld cycles\n", h[0], h[1]);
+    for (int mode = 0; mode < 2; mode++) {
+        hipMemset(out, 0, 64 * 8);
+        hipLaunchKernelGGL(k4, dim3(1), dim3(1024), 0, 0, out, (const uint64_t*)g, (uint64_t*)sink, 10, mode);
+        hipDeviceSynchronize();
+        hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost);
+        printf("walk_chain 10 links inside a 1024-thread workgroup, %s: %lld cycles\n", mode ? "all 16 waves walking" : "15 waves waiting at the barrier", h[0]);
+    }
     return 0;
 }
