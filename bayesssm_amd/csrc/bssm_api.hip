@@ -658,13 +658,15 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (N <= 0) ARGFAIL("num_particles must be a positive count");
     if (N > EB) { g_err = "bssm_pf_run_batch: a batched filter holds at most 2048 particles (one workgroup); use bssm_pf_run"; return BSSM_ERR_CAPACITY; }
     if (T < 0) ARGFAIL("bssm_pf_run_batch: T must be >= 0");
-    if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN) ARGFAIL("bssm_pf_run_batch: built-in scalar models only (linear-Gaussian, AR1+sin)");
+    if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN && cfg->model != BSSM_MODEL_SIR) ARGFAIL("bssm_pf_run_batch: unknown model");
+    const bool sir = cfg->model == BSSM_MODEL_SIR;
+    const int dim = sir ? 2 : 1;
     if (cfg->algorithm != BSSM_BPF) ARGFAIL("bssm_pf_run_batch: bootstrap filter only");
     if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run_batch: unknown resample_algorithm");
     if (cfg->resample_fn != BSSM_STRATIFIED && cfg->resample_fn != BSSM_SYSTEMATIC) ARGFAIL("bssm_pf_run_batch: stratified or systematic resampling only");
     if (cfg->z_init || cfg->z_trans || cfg->u_res || cfg->return_particles || cfg->return_ancestors)
         ARGFAIL("bssm_pf_run_batch: injected draws and histories are not available in the batched path");
-    if (cfg->n_theta < 3) ARGFAIL("bssm_pf_run_batch: theta rows must hold (phi, sigma_x, sigma_y)");
+    if (cfg->n_theta < (sir ? 5 : 3)) ARGFAIL("bssm_pf_run_batch: theta rows must hold (phi, sigma_x, sigma_y) or (lambda, gamma, n_total, s0, i0)");
     if (T > 0 && !cfg->y) ARGFAIL("bssm_pf_run_batch: y is NULL");
     if (!res->loglike) ARGFAIL("bssm_pf_run_batch: loglike buffer missing");
     for (int i = 0; i < T; i++) if (!isfinite(cfg->y[i])) ARGFAIL("Assertion on 'y' failed: Contains missing values");
@@ -679,7 +681,14 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     const int nth = cfg->n_theta;
     void *d_y, *d_ot = nullptr, *d_th, *d_keys, *d_ll, *d_se, *d_ess, *d_llh, *d_dead, *d_flags, *d_res;
     int rc;
-    const size_t rowsT1 = (size_t)F * (T + 1) * 8, rowsT = (size_t)F * std::max(T, 1) * 8;
+    const size_t rowsT1 = (size_t)F * (T + 1) * 8, rowsT = (size_t)F * std::max(T, 1) * 8, rowsSe = rowsT1 * dim;
+    void* d_lgy = nullptr;
+    if (sir) {
+        if ((rc = pool_get(c, "b_lgy", (size_t)std::max(T, 1) * 8, &d_lgy))) return rc;
+        std::vector<double> lgy((size_t)std::max(T, 1));
+        for (int i = 0; i < T; i++) lgy[i] = lgamma(cfg->y[i] + 1.0);
+        HIPCHK(hipMemcpy(d_lgy, lgy.data(), (size_t)std::max(T, 1) * 8, hipMemcpyHostToDevice));
+    }
     if ((rc = pool_get(c, "b_y", (size_t)std::max(T, 1) * 8, &d_y))) return rc;
     if (cfg->obs_times && (rc = pool_get(c, "b_ot", (size_t)std::max(T, 1) * 4, &d_ot))) return rc;
     if ((rc = pool_get(c, "b_th", (size_t)F * nth * 8, &d_th))) return rc;
@@ -687,7 +696,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     void* d_lsy;
     if ((rc = pool_get(c, "b_lsy", (size_t)F * 8, &d_lsy))) return rc;
     if ((rc = pool_get(c, "b_ll", (size_t)F * 8, &d_ll))) return rc;
-    if ((rc = pool_get(c, "b_se", rowsT1, &d_se))) return rc;
+    if ((rc = pool_get(c, "b_se", rowsSe, &d_se))) return rc;
     if ((rc = pool_get(c, "b_ess", rowsT1, &d_ess))) return rc;
     if ((rc = pool_get(c, "b_llh", rowsT, &d_llh))) return rc;
     if ((rc = pool_get(c, "b_dead", (size_t)F * 4, &d_dead))) return rc;
@@ -701,14 +710,14 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (d_ot && T > 0) HIPCHK(hipMemcpyAsync(d_ot, cfg->obs_times, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_th, thetas, (size_t)F * nth * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_keys, keys.data(), (size_t)F * sizeof(PhiloxKey), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(d_se, 0, rowsT1, c->stream));
+    HIPCHK(hipMemsetAsync(d_se, 0, rowsSe, c->stream));
     HIPCHK(hipMemsetAsync(d_ess, 0, rowsT1, c->stream));
     HIPCHK(hipMemsetAsync(d_llh, 0, rowsT, c->stream));
     BatchArgs g;
     g.N = (int)N; g.T = T; g.resample_algorithm = cfg->resample_algorithm; g.resample_fn = cfg->resample_fn;
     g.lim = g_debug_lim > 0 ? g_debug_lim : rec_window(N);
     g.lit_max = g_batch_lit_max;
-    g.threshold = threshold; g.y = (const double*)d_y; g.obs_times = (const int*)d_ot;
+    g.threshold = threshold; g.y = (const double*)d_y; g.obs_times = (const int*)d_ot; g.lgy = (const double*)d_lgy;
     g.theta = (const double*)d_th; g.theta_stride = nth; g.log_sy = (const double*)d_lsy; g.keys = (const PhiloxKey*)d_keys;
     g.loglike = (double*)d_ll; g.state_est = (double*)d_se; g.ess = (double*)d_ess; g.llh = (double*)d_llh;
     g.dead = (int*)d_dead; g.flags = (uint32_t*)d_flags; g.res_calls = (int*)d_res;
@@ -717,7 +726,8 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (g_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 64, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 64, c->stream)); g.phase_cycles = (long long*)d_ph; }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_pf_batch", k_pf_batch<0>, F, NT, 0, g);
-    else LAUNCH(c, "k_pf_batch", k_pf_batch<1>, F, NT, 0, g);
+    else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_pf_batch", k_pf_batch<1>, F, NT, 0, g);
+    else LAUNCH(c, "k_pf_batch<sir>", k_pf_batch<2>, F, NT, 0, g);
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipGetLastError());
     std::vector<int> dead((size_t)F), nres((size_t)F);
@@ -726,7 +736,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     HIPCHK(hipMemcpyAsync(dead.data(), d_dead, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(flags.data(), d_flags, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(nres.data(), d_res, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
-    if (res->state_est) HIPCHK(hipMemcpyAsync(res->state_est, d_se, rowsT1, hipMemcpyDeviceToHost, c->stream));
+    if (res->state_est) HIPCHK(hipMemcpyAsync(res->state_est, d_se, rowsSe, hipMemcpyDeviceToHost, c->stream));
     if (res->ess) HIPCHK(hipMemcpyAsync(res->ess, d_ess, rowsT1, hipMemcpyDeviceToHost, c->stream));
     if (res->loglike_history && T > 0) HIPCHK(hipMemcpyAsync(res->loglike_history, d_llh, (size_t)F * T * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -741,7 +751,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
         if (dead[f]) {                                // the reference returns at once: later rows keep their initial values (:90-97)
             for (int i = dead[f]; i <= T; i++) {
                 if (res->ess) res->ess[(size_t)f * (T + 1) + i] = 0.0;
-                if (res->state_est) res->state_est[(size_t)f * (T + 1) + i] = 0.0;
+                if (res->state_est) for (int d = 0; d < dim; d++) res->state_est[((size_t)f * (T + 1) + i) * dim + d] = 0.0;
             }
             if (res->loglike_history) for (int i = dead[f]; i < T; i++) res->loglike_history[(size_t)f * T + i] = 0.0;
         }
@@ -922,7 +932,8 @@ extern "C" int bssm_pmmh_chains_batch(bssm_ctx* c, int n_chains, const bssm_pmmh
     }
     bssm_pf_config pf = pf0;
     pf.n_theta = nth; pf.theta = nullptr; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
-    std::vector<double> thetas((size_t)n_chains * nth), ll((size_t)n_chains), se((size_t)n_chains * (T + 1));
+    const int dim = ch[0].dim;
+    std::vector<double> thetas((size_t)n_chains * nth), ll((size_t)n_chains), se((size_t)n_chains * (T + 1) * dim);
     std::vector<unsigned long long> seeds((size_t)n_chains), streams((size_t)n_chains);
     std::vector<int> who((size_t)n_chains);
     double ms = 0, ms_total = 0;
@@ -944,7 +955,7 @@ extern "C" int bssm_pmmh_chains_batch(bssm_ctx* c, int n_chains, const bssm_pmmh
         for (int f = 0; f < F; f++) {
             ChainState& s = ch[who[f]];
             std::vector<double>& dst = (i == 0) ? s.se_cur : s.se_prop;
-            memcpy(dst.data(), se.data() + (size_t)f * (T + 1), sizeof(double) * (T + 1));
+            memcpy(dst.data(), se.data() + (size_t)f * (T + 1) * dim, sizeof(double) * (T + 1) * dim);
             if (i == 0) s.start(ll[f]); else s.finish(i, ll[f]);
         }
     }

@@ -1801,10 +1801,11 @@ struct BatchArgs {
     int lit_max;                                      // N <= lit_max: exact sums by the in-order pass (block_literal_terms)
     double threshold;
     const double* y; const int* obs_times;            // [T]; obs_times may be nullptr (1..T)
+    const double* lgy;                                // [T] lgamma(y + 1) (SIR's Poisson observation density), or nullptr
     const double* theta; int theta_stride;            // [F][theta_stride]: phi, sigma_x, sigma_y
     const double* log_sy;                             // [F] log(sigma_y), taken on the host like bssm_pf_run does (device log may differ in the last bit)
     const PhiloxKey* keys;                            // [F]
-    double* loglike; double* state_est; double* ess; double* llh;    // [F], [F][T+1], [F][T+1], [F][T]
+    double* loglike; double* state_est; double* ess; double* llh;    // [F], [F][T+1][D], [F][T+1], [F][T]
     int* dead; uint32_t* flags; int* res_calls;       // [F]
     long long* phase_cycles;                          // dev tool: [8] cycles per phase summed over filter 0's observations, or nullptr
 };
@@ -1826,19 +1827,35 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
         l0[r] = -INFINITY; l1[r] = -INFINITY;
         if (j < N) {
             const bool two = (j + 1 < N);
-            double x0 = x[j], x1 = two ? x[j + 1] : 0.0;
-            if (TRANS) {
-                double z0, z1;
-                normal_pair(ns.key, ns.purpose, ns.call, 0, (uint32_t)(j >> 1), z0, z1);
-                x0 = Model<MODEL>::transition(x0, z0, par);
-                x1 = Model<MODEL>::transition(x1, z1, par);
-                x[j] = x0; if (two) x[j + 1] = x1;
-            }
-            if (WEIGHT) {
-                l0[r] = r_dnorm_log(y, x0, par.sy, par.log_sy);
-                l1[r] = r_dnorm_log(y, x1, par.sy, par.log_sy);
-                lw[j] = l0[r];
-                if (two) lw[j + 1] = l1[r]; else l1[r] = -INFINITY;
+            if constexpr (MODEL == 2) {       // k_step_sir: state (s, i) as [2][N]
+                double s0 = x[j], i0 = x[N + j];
+                double s1 = two ? x[j + 1] : 0.0, i1 = two ? x[N + j + 1] : 0.0;
+                if (TRANS) {
+                    Sir::transition(s0, i0, par, ns.key, ns.call, (uint32_t)j);
+                    if (two) Sir::transition(s1, i1, par, ns.key, ns.call, (uint32_t)(j + 1));
+                    x[j] = s0; x[N + j] = i0;
+                    if (two) { x[j + 1] = s1; x[N + j + 1] = i1; }
+                }
+                if (WEIGHT) {
+                    l0[r] = Sir::loglik(y, i0, par); l1[r] = Sir::loglik(y, i1, par);
+                    lw[j] = l0[r];
+                    if (two) lw[j + 1] = l1[r]; else l1[r] = -INFINITY;
+                }
+            } else {
+                double x0 = x[j], x1 = two ? x[j + 1] : 0.0;
+                if (TRANS) {
+                    double z0, z1;
+                    normal_pair(ns.key, ns.purpose, ns.call, 0, (uint32_t)(j >> 1), z0, z1);
+                    x0 = Model<MODEL>::transition(x0, z0, par);
+                    x1 = Model<MODEL>::transition(x1, z1, par);
+                    x[j] = x0; if (two) x[j + 1] = x1;
+                }
+                if (WEIGHT) {
+                    l0[r] = r_dnorm_log(y, x0, par.sy, par.log_sy);
+                    l1[r] = r_dnorm_log(y, x1, par.sy, par.log_sy);
+                    lw[j] = l0[r];
+                    if (two) lw[j + 1] = l1[r]; else l1[r] = -INFINITY;
+                }
             }
         }
     }
@@ -1888,7 +1905,7 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
 }
 
 template <int MODEL>
-__global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
+__global__ __launch_bounds__(NT, (MODEL == 2) ? 1 : 2) void k_pf_batch(BatchArgs g)
 {
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT + 1];
@@ -1896,12 +1913,14 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
     __shared__ int Tbegin;
     __shared__ double es[NT];
     __shared__ double sh16[NTS / 64];
-    __shared__ __attribute__((aligned(16))) double XA[EB];
-    __shared__ __attribute__((aligned(16))) double XB[EB];
+    constexpr int D = (MODEL == 2) ? 2 : 1;                      // state dimension; particles are [D][N]
+    __shared__ __attribute__((aligned(16))) double XA[D * EB];
+    __shared__ __attribute__((aligned(16))) double XB[D * EB];
     __shared__ __attribute__((aligned(16))) double LW[EB];      // log-weights, then (in place) the normalised weights
     __shared__ DevState st;
     __shared__ BlockRec br;
-    __shared__ double pm1, ps1, pq1, ainw1, ainp1, sep;
+    __shared__ double pm1, ps1, pq1, ainw1, ainp1;
+    __shared__ double sep[2];
     __shared__ uint64_t cin1;
     const int fi = blockIdx.x, t = threadIdx.x;
     const long long N = g.N;
@@ -1911,6 +1930,7 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
         const double* th = g.theta + (long long)fi * g.theta_stride;
         par.phi = th[0]; par.sx = th[1]; par.sy = th[2]; par.log_sy = g.log_sy[fi];
         par.n_total = 0.0; par.s0 = 0.0; par.i0 = 0.0; par.lgy = 0.0;
+        if (MODEL == 2) { par.n_total = th[2]; par.s0 = th[3]; par.i0 = th[4]; }      // SIR: (lambda, gamma, n_total, s0, i0)
     }
     const PhiloxKey key = g.keys[fi];
     const bool lit = g.N <= g.lit_max;      // few terms: the in-order pass beats the record machinery's fixed latency
@@ -1918,15 +1938,15 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
         st.loglike = 0.0; st.lse_max = 0.0; st.lse_sum = 0.0; st.ess = 0.0; st.total_bits = 0;
         st.do_resample = 0; st.dead = 0; st.flags = 0; st.res_calls = 0; st.cur_call = 0; st.debug_stop = 0;
         st.stat_hard_blocks = 0; st.stat_serial_walks = 0; st.stat_literal_terms = 0;
-        sep = 0.0;
+        sep[0] = 0.0; sep[1] = 0.0;
     }
     __syncthreads();
     {   // t = 0  (R/particle_filter_core.R:76-116)
         NoiseSrc ns; ns.arr = nullptr; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
-        init_block(sm.sh4, 0, XA, N, ns, &sep, MODEL, par);
+        init_block(sm.sh4, 0, XA, N, ns, sep, MODEL, par);
     }
     __syncthreads();
-    if (t == 0 && g.state_est) { double s0 = 0.0; s0 += sep; g.state_est[(long long)fi * (T + 1)] = s0; }
+    if (t == 0 && g.state_est) { for (int d = 0; d < D; d++) { double s0 = 0.0; s0 += sep[d]; g.state_est[(long long)fi * (T + 1) * D + d] = s0; } }
     double* xa = XA; double* xb = XB;
     long long ph[6] = {0, 0, 0, 0, 0, 0};
     const bool prof = (g.phase_cycles != nullptr) && fi == 0 && t == 0;
@@ -1937,6 +1957,7 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
         const int gap = ot - prev_t;                                                      // :124
         prev_t = ot;
         const double yi = g.y[i - 1];
+        if (MODEL == 2) par.lgy = g.lgy[i - 1];                  // lgamma(y + 1), taken on the host like bssm_pf_run does
         long long pc = prof ? clock64() : 0;
         NoiseSrc ns; ns.arr = nullptr; ns.key = key; ns.purpose = DRAW_TRANS;
         for (int step = 1; step <= gap; step++) {                                         // :125-136
@@ -1952,7 +1973,7 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
             __syncthreads();
         }
         PH(0)
-        if (t == 0) sep = 0.0;
+        if (t == 0) { sep[0] = 0.0; sep[1] = 0.0; }
         FromLw fl;
         fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.ain_out = &ainw1;
         fl.plan = PLAN_PF; fl.N = N; fl.obs_i = i; fl.resample_algorithm = g.resample_algorithm; fl.threshold = g.threshold;
@@ -1974,7 +1995,7 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
         ApplyArgs a;
         a.w = LW; a.nw = N; a.ain_p = &ainp1; a.cin = &cin1; a.lim = g.lim; a.n = (int)N;
         a.u_base = nullptr; a.u_stride = 0; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;
-        a.xsrc = xa; a.xdst = xb; a.dim = 1; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = &sep;
+        a.xsrc = xa; a.xdst = xb; a.dim = D; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = sep;
         if (g.resample_fn == 1) {                                                         // systematic
             if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
         } else {                                                                          // stratified
@@ -1983,11 +2004,11 @@ __global__ __launch_bounds__(NT, 2) void k_pf_batch(BatchArgs g)
         __syncthreads();
         PH(2)
         if (g.resample_algorithm != 1) {                 // SIS / SISAR: carry over when no resample ran (:238)
-            carry_block(sm.sh4, 0, xa, xb, LW, N, 1, &sep, &st);
+            carry_block(sm.sh4, 0, xa, xb, LW, N, D, sep, &st);
             __syncthreads();
         }
         { double* tmp = xa; xa = xb; xb = tmp; }
-        if (t == 0 && g.state_est) { double s0 = 0.0; s0 += sep; g.state_est[(long long)fi * (T + 1) + i] = s0; }   // :237-241
+        if (t == 0 && g.state_est) { for (int d = 0; d < D; d++) { double s0 = 0.0; s0 += sep[d]; g.state_est[((long long)fi * (T + 1) + i) * D + d] = s0; } }   // :237-241
         if (st.dead) break;                              // degenerate weights: the reference returns at once (:189-202)
         __syncthreads();
         PH(3)

@@ -139,15 +139,17 @@ def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelih
         if ot.size != T or (T and (ot[0] < 1 or np.any(np.diff(ot) < 0))):
             raise ValueError("Assertion on 'obs_times' failed")
     thetas = np.ascontiguousarray(thetas, dtype=np.float64)
-    if thetas.ndim != 2 or thetas.shape[1] < 3:
-        raise ValueError("thetas must be an (n_filters, 3) array of (phi, sigma_x, sigma_y)")
+    dim = models.dim_of(model)
+    if thetas.ndim != 2 or thetas.shape[1] < (5 if model == "sir" else 3):
+        raise ValueError("thetas must be an (n_filters, 3) array of (phi, sigma_x, sigma_y) "
+                         "[SIR: (n_filters, 5) of (lambda, gamma, n_total, s0, i0)]")
     F = int(thetas.shape[0])
     seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (F,)))
     streams = np.arange(F, dtype=np.uint64) if streams is None else \
         np.ascontiguousarray(np.broadcast_to(np.asarray(streams, dtype=np.uint64), (F,)))
     ctx = ctx or _lib.default_context(N, dim=1)
     ll = np.zeros(F)
-    se = np.zeros((F, T + 1))
+    se = np.zeros((F, T + 1, dim)) if dim > 1 else np.zeros((F, T + 1))
     ess = np.zeros((F, T + 1))
     llh = np.zeros((F, max(T, 1)))
     ers = np.zeros(F, dtype=np.int32)

@@ -229,7 +229,7 @@ def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov
 def batch_eligible(pf_wrapper, model, num_particles, resample_fn):
     """Can this filter configuration run in the one-workgroup-per-filter kernel (bssm_pf_run_batch)?"""
     from .filters import batch_max_particles
-    return (pf_wrapper is not auxiliary_filter and models.dim_of(model) == 1 and model in ("lg", "ar1sin")
+    return (pf_wrapper is not auxiliary_filter and model in ("lg", "ar1sin", "sir")
             and resample_fn in ("stratified", "systematic") and int(num_particles) <= batch_max_particles())
 
 
@@ -260,7 +260,8 @@ def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, prop
                                     ptr(pb), int(seeds[k]), int(chain_indices[k]), 1 if return_latent_state_est else 0))
         theta_chain = np.zeros((m, n_params))
         ll_chain = np.zeros(m)
-        se_chain = np.zeros((m, T + 1)) if return_latent_state_est else None
+        dim = models.dim_of(model)
+        se_chain = (np.zeros((m, T + 1, dim)) if dim > 1 else np.zeros((m, T + 1))) if return_latent_state_est else None
         acc = np.zeros(1, dtype=np.int32)
         ms = np.zeros(1)
         ress.append(_lib.PmmhResult(ptr(theta_chain), ptr(ll_chain), ptr(se_chain), ptr(acc), ptr(ms)))

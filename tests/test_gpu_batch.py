@@ -176,3 +176,56 @@ def test_pmmh_pilot_batched_matches_unbatched():
         assert pa["target_n"] == pc["target_n"] and pa["variance_estimate"] == pc["variance_estimate"]
     for k in ("phi", "sigma_x", "sigma_y"):
         assert (a["theta_chain"][k] == c["theta_chain"][k]).all()
+
+
+@pytest.mark.parametrize("N", [50, 500, 2048])
+@pytest.mark.parametrize("ra,rf", [("SISAR", "stratified"), ("SISR", "systematic")])
+def test_batch_sir_matches_single_bitwise(N, ra, rf):
+    """The stochastic SIR model (state (s, i), Gillespie transition, Poisson observations) through the batched kernel:
+    bit-identical to bssm_pf_run, both state-estimate components."""
+    import bayesssm_amd as b
+    sys_path = __import__("sys").path
+    sys_path.insert(0, __import__("os").path.dirname(__file__))
+    from test_gpu_sir import _simulate
+    ys = _simulate(np.random.default_rng(1405), 15)
+    m = b.models.sir()
+    thetas = np.array([[0.5, 0.2, 500.0, 430.0, 70.0], [0.35, 0.3, 500.0, 430.0, 70.0], [0.8, 0.1, 500.0, 430.0, 70.0]])
+    out = b.bootstrap_filter_batch(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 9, [5, 6, 7],
+                                   resample_algorithm=ra, resample_fn=rf)
+    assert out["state_est"].shape == (3, 16, 2) and np.all(out["status"] == 0)
+    for k in range(3):
+        ref = b.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, return_particles=False, seed=9,
+                                 stream=5 + k, resample_algorithm=ra, resample_fn=rf, lambda_=thetas[k][0], gamma=thetas[k][1])
+        assert out["loglike"][k] == ref["loglike"]
+        np.testing.assert_array_equal(out["loglike_history"][k], ref["loglike_history"])
+        np.testing.assert_array_equal(out["ess"][k], ref["ess"])
+        np.testing.assert_array_equal(out["state_est"][k], ref["state_est"])
+
+
+def test_pmmh_sir_lockstep_matches_per_chain():
+    """PMMH over (lambda, gamma) of the SIR model with the vignette's half-normal priors
+    (vignettes/articles/stochastic-sir-model.Rmd:267-274), chains in lock-step vs one at a time."""
+    import warnings
+    import bayesssm_amd as b
+    sys_path = __import__("sys").path
+    sys_path.insert(0, __import__("os").path.dirname(__file__))
+    from test_gpu_sir import _simulate
+    ys = _simulate(np.random.default_rng(7), 12)
+    m = b.models.sir()
+    kw = dict(pf_wrapper=b.bootstrap_filter, y=ys, m=40, init_fn=m.init_fn, transition_fn=m.transition_fn,
+              log_likelihood_fn=m.log_likelihood_fn,
+              log_priors={"lambda": b.prior_halfnormal(1), "gamma": b.prior_halfnormal(2)},
+              pilot_init_params=[{"lambda": 0.4 + 0.05 * c, "gamma": 0.25} for c in range(3)],
+              burn_in=5, num_chains=3, seed=4, param_transform={"lambda": "log", "gamma": "log"},
+              num_particles=300, proposal_cov=np.diag([4e-3, 4e-3]), return_latent_state_est=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = b.pmmh(batch_chains=False, chains_per_gpu=1, **kw)
+        c = b.pmmh(batch_chains=True, **kw)
+    for k in ("chain", "lambda", "gamma"):
+        assert (a["theta_chain"][k] == c["theta_chain"][k]).all()
+    for ch in range(3):
+        ea, ec = a["_extras"]["local_chains"][ch], c["_extras"]["local_chains"][ch]
+        assert ec.get("batched") and ec["state_est_chain"].shape == (40, 13, 2)
+        np.testing.assert_array_equal(ea["state_est_chain"], ec["state_est_chain"])
+        np.testing.assert_array_equal(ea["loglike_chain"], ec["loglike_chain"])
