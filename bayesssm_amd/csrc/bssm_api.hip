@@ -661,7 +661,8 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN && cfg->model != BSSM_MODEL_SIR) ARGFAIL("bssm_pf_run_batch: unknown model");
     const bool sir = cfg->model == BSSM_MODEL_SIR;
     const int dim = sir ? 2 : 1;
-    if (cfg->algorithm != BSSM_BPF) ARGFAIL("bssm_pf_run_batch: bootstrap filter only");
+    if (cfg->algorithm != BSSM_BPF && cfg->algorithm != BSSM_APF) ARGFAIL("bssm_pf_run_batch: bootstrap and auxiliary filters only");
+    const bool apf = cfg->algorithm == BSSM_APF;
     if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run_batch: unknown resample_algorithm");
     if (cfg->resample_fn != BSSM_STRATIFIED && cfg->resample_fn != BSSM_SYSTEMATIC) ARGFAIL("bssm_pf_run_batch: stratified or systematic resampling only");
     if (cfg->z_init || cfg->z_trans || cfg->u_res || cfg->return_particles || cfg->return_ancestors)
@@ -725,9 +726,15 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     void* d_ph = nullptr;
     if (g_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 64, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 64, c->stream)); g.phase_cycles = (long long*)d_ph; }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_pf_batch", k_pf_batch<0>, F, NT, 0, g);
-    else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_pf_batch", k_pf_batch<1>, F, NT, 0, g);
-    else LAUNCH(c, "k_pf_batch<sir>", k_pf_batch<2>, F, NT, 0, g);
+    if (!apf) {
+        if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_pf_batch", (k_pf_batch<0, false>), F, NT, 0, g);
+        else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_pf_batch", (k_pf_batch<1, false>), F, NT, 0, g);
+        else LAUNCH(c, "k_pf_batch<sir>", (k_pf_batch<2, false>), F, NT, 0, g);
+    } else {
+        if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_pf_batch<apf>", (k_pf_batch<0, true>), F, NT, 0, g);
+        else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_pf_batch<apf>", (k_pf_batch<1, true>), F, NT, 0, g);
+        else LAUNCH(c, "k_pf_batch<sir,apf>", (k_pf_batch<2, true>), F, NT, 0, g);
+    }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipGetLastError());
     std::vector<int> dead((size_t)F), nres((size_t)F);

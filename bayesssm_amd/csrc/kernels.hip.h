@@ -1812,9 +1812,9 @@ struct BatchArgs {
 
 // k_step<MODEL, TRANS, WEIGHT, false> for one block of up to EB particles, by NT threads: thread t plays the threads
 // t, t + NT, t + 2 NT, t + 3 NT of the NTS-thread kernel (wave w of round r = wave w + 4 r there).
-template <int MODEL, bool TRANS, int WEIGHT>
-__device__ __forceinline__ void step_emul(double* sh16, double* x, double* __restrict__ lw, long long N, const ModelPar& par, double y,
-                                          const NoiseSrc& ns, double* pm, double* ps, double* pq)
+template <int MODEL, bool TRANS, int WEIGHT, bool SUBAUX = false>
+__device__ __forceinline__ void step_emul(double* sh16, double* x, double* __restrict__ lw, const double* __restrict__ auxg, long long N,
+                                          const ModelPar& par, double y, const NoiseSrc& ns, double* pm, double* ps, double* pq)
 {
     constexpr int R = NTS / NT;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1837,7 +1837,9 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
                     if (two) { x[j + 1] = s1; x[N + j + 1] = i1; }
                 }
                 if (WEIGHT) {
-                    l0[r] = Sir::loglik(y, i0, par); l1[r] = Sir::loglik(y, i1, par);
+                    if (WEIGHT == 2) { l0[r] = Sir::aux_loglik(y, s0, i0, par); l1[r] = Sir::aux_loglik(y, s1, i1, par); }
+                    else { l0[r] = Sir::loglik(y, i0, par); l1[r] = Sir::loglik(y, i1, par); }
+                    if (SUBAUX) { l0[r] = l0[r] - auxg[j]; if (two) l1[r] = l1[r] - auxg[j + 1]; }
                     lw[j] = l0[r];
                     if (two) lw[j + 1] = l1[r]; else l1[r] = -INFINITY;
                 }
@@ -1851,8 +1853,14 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
                     x[j] = x0; if (two) x[j + 1] = x1;
                 }
                 if (WEIGHT) {
-                    l0[r] = r_dnorm_log(y, x0, par.sy, par.log_sy);
-                    l1[r] = r_dnorm_log(y, x1, par.sy, par.log_sy);
+                    if (WEIGHT == 2) {
+                        l0[r] = r_dnorm_log(y, Model<MODEL>::forecast(x0, par), par.sy, par.log_sy);
+                        l1[r] = r_dnorm_log(y, Model<MODEL>::forecast(x1, par), par.sy, par.log_sy);
+                    } else {
+                        l0[r] = r_dnorm_log(y, x0, par.sy, par.log_sy);
+                        l1[r] = r_dnorm_log(y, x1, par.sy, par.log_sy);
+                    }
+                    if (SUBAUX) { l0[r] = l0[r] - auxg[j]; if (two) l1[r] = l1[r] - auxg[j + 1]; }
                     lw[j] = l0[r];
                     if (two) lw[j + 1] = l1[r]; else l1[r] = -INFINITY;
                 }
@@ -1904,8 +1912,8 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
     }
 }
 
-template <int MODEL>
-__global__ __launch_bounds__(NT, (MODEL == 2) ? 1 : 2) void k_pf_batch(BatchArgs g)
+template <int MODEL, bool APF>
+__global__ __launch_bounds__(NT, (MODEL == 2 || APF) ? 1 : 2) void k_pf_batch(BatchArgs g)
 {
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT + 1];
@@ -1917,6 +1925,8 @@ __global__ __launch_bounds__(NT, (MODEL == 2) ? 1 : 2) void k_pf_batch(BatchArgs
     __shared__ __attribute__((aligned(16))) double XA[D * EB];
     __shared__ __attribute__((aligned(16))) double XB[D * EB];
     __shared__ __attribute__((aligned(16))) double LW[EB];      // log-weights, then (in place) the normalised weights
+    __shared__ __attribute__((aligned(16))) double AUXLW[APF ? EB : 2];     // auxiliary filter: first-stage log-weights ...
+    __shared__ __attribute__((aligned(16))) double AUXG[APF ? EB : 2];      // ... and their gather through the first-stage ancestors
     __shared__ DevState st;
     __shared__ BlockRec br;
     __shared__ double pm1, ps1, pq1, ainw1, ainp1;
@@ -1962,17 +1972,53 @@ __global__ __launch_bounds__(NT, (MODEL == 2) ? 1 : 2) void k_pf_batch(BatchArgs
         NoiseSrc ns; ns.arr = nullptr; ns.key = key; ns.purpose = DRAW_TRANS;
         for (int step = 1; step <= gap; step++) {                                         // :125-136
             ns.call = (uint32_t)ktrans;
-            if (step == gap) step_emul<MODEL, true, 1>(sh16, xa, LW, N, par, yi, ns, &pm1, &ps1, &pq1);
-            else step_emul<MODEL, true, 0>(sh16, xa, LW, N, par, yi, ns, &pm1, &ps1, &pq1);
+            if (!APF && step == gap) step_emul<MODEL, true, 1>(sh16, xa, LW, nullptr, N, par, yi, ns, &pm1, &ps1, &pq1);
+            else step_emul<MODEL, true, 0>(sh16, xa, LW, nullptr, N, par, yi, ns, &pm1, &ps1, &pq1);
             ktrans++;
             __syncthreads();
         }
-        if (gap <= 0) {                                  // obs_times repeats a time: weights on the current particles
+        if (APF) {                                                                        // :140-175
+            // first stage: look-ahead weights at the current particles, resample particles and carry the log-weights along
             ns.call = 0;
-            step_emul<MODEL, false, 1>(sh16, xa, LW, N, par, yi, ns, &pm1, &ps1, &pq1);
+            step_emul<MODEL, false, 2>(sh16, xa, AUXLW, nullptr, N, par, yi, ns, &pm1, &ps1, &pq1);
+            __syncthreads();
+            FromLw fa;
+            fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.ain_out = &ainw1;
+            fa.plan = PLAN_AUX; fa.N = N; fa.obs_i = i; fa.resample_algorithm = g.resample_algorithm; fa.threshold = g.threshold;
+            fa.ess_out = nullptr; fa.llh_out = nullptr; fa.resampled_out = nullptr;
+            if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa);
+            else local_block<MODE_W, true, NT, false>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa);
+            __syncthreads();
+            if (t == 0 && !st.dead && !st.flags && st.do_resample) {
+                const uint64_t fs = br.prefix.o[0];
+                const double tot = b2d(fs);
+                st.total_bits = fs;
+                if (tot == 0.0) st.flags |= FLAG_ZERO_SUM;
+                if (!isfinite(tot)) st.flags |= FLAG_NONFINITE;
+                ainp1 = ainw1 / tot; cin1 = 0;
+            }
+            __syncthreads();
+            ApplyArgs aa;
+            aa.w = LW; aa.nw = N; aa.ain_p = &ainp1; aa.cin = &cin1; aa.lim = g.lim; aa.n = (int)N;
+            aa.u_base = nullptr; aa.u_stride = 0; aa.key = key; aa.anc_out = nullptr; aa.anc_stride = 0; aa.cum_out = nullptr;
+            aa.xsrc = xa; aa.xdst = xb; aa.dim = D; aa.xstride = N; aa.auxsrc = AUXLW; aa.auxdst = AUXG; aa.se_part = nullptr;
+            if (g.resample_fn == 1) {
+                if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, aa, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, aa, &st);
+            } else {
+                if (lit) apply_block<0, true>(sm, tin, Tl, Tbegin, 0, 1, aa, &st); else apply_block<0, false>(sm, tin, Tl, Tbegin, 0, 1, aa, &st);
+            }
+            __syncthreads();
+            { double* tmp = xa; xa = xb; xb = tmp; }
+            // second stage: propagate the resampled particles, weight by  loglik - aux_lw[ancestor]   (:159-175)
+            ns.call = (uint32_t)ktrans;
+            step_emul<MODEL, true, 1, true>(sh16, xa, LW, AUXG, N, par, yi, ns, &pm1, &ps1, &pq1);
+            ktrans++;
+            __syncthreads();
+        } else if (gap <= 0) {                           // obs_times repeats a time: weights on the current particles
+            ns.call = 0;
+            step_emul<MODEL, false, 1>(sh16, xa, LW, nullptr, N, par, yi, ns, &pm1, &ps1, &pq1);
             __syncthreads();
         }
-        PH(0)
         if (t == 0) { sep[0] = 0.0; sep[1] = 0.0; }
         FromLw fl;
         fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.ain_out = &ainw1;

@@ -113,8 +113,18 @@ def batch_max_particles():
     return int(_lib.load().bssm_pf_batch_max_particles())
 
 
+def auxiliary_filter_batch(y, num_particles, init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn, thetas,
+                           seeds=0, streams=None, **kw):
+    """bootstrap_filter_batch for auxiliary_filter (R/auxiliary_filter.R:163-216): filter k equals
+    auxiliary_filter(..., seed=seeds[k], stream=streams[k], return_particles=False) bit for bit."""
+    models.resolve(init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn)
+    return bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelihood_fn, thetas, seeds, streams,
+                                  _algorithm="APF", **kw)
+
+
 def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelihood_fn, thetas, seeds=0, streams=None,
-                           obs_times=None, resample_algorithm=None, resample_fn=None, threshold=None, ctx=None):
+                           obs_times=None, resample_algorithm=None, resample_fn=None, threshold=None, ctx=None,
+                           _algorithm="BPF"):
     """Many independent bootstrap filters in ONE kernel launch (one workgroup per filter, the whole T loop on chip):
     filter k runs with thetas[k] = (phi, sigma_x, sigma_y), seeds[k], streams[k] on the shared data `y`.  Each filter
     returns exactly what bootstrap_filter(..., seed=seeds[k], stream=streams[k], return_particles=False) returns.
@@ -156,14 +166,14 @@ def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelih
     nres = np.zeros(F, dtype=np.int32)
     status = np.zeros(F, dtype=np.int32)
     ms = np.zeros(1)
-    cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM["BPF"], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
+    cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[_algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
                         _lib.RESAMPLE_FN[resample_fn], N, T, -1.0 if threshold is None else float(threshold),
                         None, int(thetas.shape[1]), _ptr(y), _ptr(ot), 0, 0, None, None, None, 0, 0, 0.0, None, None)
     res = _lib.PfBatchResult(_ptr(ll), _ptr(se), _ptr(ess), _ptr(llh), _ptr(ers), _ptr(nres), _ptr(status), _ptr(ms))
     _lib.check(_lib.load().bssm_pf_run_batch(ctx.handle, C.byref(cfg), F, _ptr(thetas), _ptr(seeds), _ptr(streams),
                                              C.byref(res)))
     return {"loglike": ll, "state_est": se, "ess": ess, "loglike_history": llh[:, :T], "early_return_step": ers,
-            "n_res_calls": nres, "status": status, "device_ms": float(ms[0]), "algorithm": "BPF"}
+            "n_res_calls": nres, "status": status, "device_ms": float(ms[0]), "algorithm": _algorithm}
 
 
 def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn, obs_times=None,

@@ -229,7 +229,7 @@ def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov
 def batch_eligible(pf_wrapper, model, num_particles, resample_fn):
     """Can this filter configuration run in the one-workgroup-per-filter kernel (bssm_pf_run_batch)?"""
     from .filters import batch_max_particles
-    return (pf_wrapper is not auxiliary_filter and model in ("lg", "ar1sin", "sir")
+    return (model in ("lg", "ar1sin", "sir")
             and resample_fn in ("stratified", "systematic") and int(num_particles) <= batch_max_particles())
 
 
@@ -253,7 +253,8 @@ def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, prop
         init_theta = np.ascontiguousarray(init_thetas[k], dtype=np.float64)
         cov = np.ascontiguousarray(proposal_covs[k], dtype=np.float64).reshape(n_params, n_params)
         consts = np.ascontiguousarray(list(init_theta) + list(model_constants or ()), dtype=np.float64)
-        pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM["BPF"], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
+        pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM["APF" if pf_wrapper is auxiliary_filter else "BPF"],
+                           _lib.RESAMPLE_ALGORITHM[resample_algorithm],
                            _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, ptr(consts), int(consts.size),
                            ptr(y), ptr(ot), int(seeds[k]), 0, None, None, None, 0, 0)
         cfgs.append(_lib.PmmhConfig(pf, int(m), int(n_params), ptr(init_theta), ptr(cov), ptr(tr), ptr(pk), ptr(pa),
@@ -385,7 +386,7 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
                 th = np.tile(np.asarray(list(theta) + owner_consts, dtype=np.float64), (len(tags), 1))
                 r = bootstrap_filter_batch(y, int(n), init_fn, transition_fn, log_likelihood_fn, th, int(seeds[_c]),
                                            [(1 << 40) + int(t) for t in tags], obs_times=obs_times,
-                                           resample_algorithm=p_ra, resample_fn=p_rf, ctx=ctx_c)
+                                           resample_algorithm=p_ra, resample_fn=p_rf, ctx=ctx_c, _algorithm=algorithm)
                 if np.any(r["status"] != 0):
                     raise ValueError(_lib.load().bssm_status_string(int(r["status"][r["status"] != 0][0])).decode())
                 return r["loglike"]
