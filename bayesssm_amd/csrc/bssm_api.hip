@@ -49,6 +49,7 @@ struct bssm_ctx {
     // growable buffers
     std::map<std::string, std::pair<void*, size_t>> pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* h_stage = nullptr; size_t h_stage_bytes = 0;      // pinned host staging (batched filters: one upload, one download)
     // profiling
     bool profile = false;
     std::map<std::string, ProfEntry> prof;
@@ -68,6 +69,17 @@ static int pool_get(bssm_ctx* c, const char* name, size_t bytes, void** out)
         e.second = want;
     }
     *out = e.first;
+    return BSSM_OK;
+}
+
+static int host_stage(bssm_ctx* c, size_t bytes)
+{
+    if (c->h_stage_bytes >= bytes) return BSSM_OK;
+    if (c->h_stage) HIPCHK(hipHostFree(c->h_stage));
+    c->h_stage = nullptr; c->h_stage_bytes = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
+    c->h_stage_bytes = want;
     return BSSM_OK;
 }
 
@@ -143,6 +155,7 @@ extern "C" void bssm_ctx_destroy(bssm_ctx* c)
                     c->ain_w, c->ain_p, c->brec, c->side, c->cin, c->st};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->pool) if (kv.second.first) (void)hipFree(kv.second.first);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto ev : c->ev_pool) (void)hipEventDestroy(ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -680,40 +693,37 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     double threshold = cfg->threshold;
     if (threshold < 0) threshold = (cfg->resample_algorithm == BSSM_SIS) ? INFINITY : (cfg->resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
     const int nth = cfg->n_theta;
-    void *d_y, *d_ot = nullptr, *d_th, *d_keys, *d_ll, *d_se, *d_ess, *d_llh, *d_dead, *d_flags, *d_res;
     int rc;
-    const size_t rowsT1 = (size_t)F * (T + 1) * 8, rowsT = (size_t)F * std::max(T, 1) * 8, rowsSe = rowsT1 * dim;
-    void* d_lgy = nullptr;
-    if (sir) {
-        if ((rc = pool_get(c, "b_lgy", (size_t)std::max(T, 1) * 8, &d_lgy))) return rc;
-        std::vector<double> lgy((size_t)std::max(T, 1));
-        for (int i = 0; i < T; i++) lgy[i] = lgamma(cfg->y[i] + 1.0);
-        HIPCHK(hipMemcpy(d_lgy, lgy.data(), (size_t)std::max(T, 1) * 8, hipMemcpyHostToDevice));
+    // One packed upload and one packed download per call (pinned staging): at T = 20 the filter itself takes ~0.3 ms,
+    // a dozen separate small copies and memsets would double that.
+    const size_t Tn = (size_t)std::max(T, 1);
+    auto up8 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_th = 0, o_lsy = o_th + up8((size_t)F * nth * 8), o_keys = o_lsy + up8((size_t)F * 8),
+                 o_y = o_keys + up8((size_t)F * sizeof(PhiloxKey)), o_lgy = o_y + up8(Tn * 8), o_ot = o_lgy + up8(Tn * 8),
+                 in_bytes = o_ot + up8(Tn * 4);
+    const size_t rowsT1 = (size_t)F * (T + 1) * 8, rowsSe = rowsT1 * dim;
+    const size_t q_ll = 0, q_se = q_ll + up8((size_t)F * 8), q_ess = q_se + up8(rowsSe), q_llh = q_ess + up8(rowsT1),
+                 q_dead = q_llh + up8((size_t)F * Tn * 8), q_flags = q_dead + up8((size_t)F * 4), q_res = q_flags + up8((size_t)F * 4),
+                 out_bytes = q_res + up8((size_t)F * 4);
+    if ((rc = host_stage(c, std::max(in_bytes, out_bytes)))) return rc;
+    void *d_in, *d_out;
+    if ((rc = pool_get(c, "b_in", in_bytes, &d_in))) return rc;
+    if ((rc = pool_get(c, "b_out", out_bytes, &d_out))) return rc;
+    char* hs = (char*)c->h_stage;
+    memcpy(hs + o_th, thetas, (size_t)F * nth * 8);
+    for (int f = 0; f < F; f++) {
+        ((double*)(hs + o_lsy))[f] = log(thetas[(size_t)f * nth + 2]);                      // as bssm_pf_run: log(sigma_y) on the host
+        ((PhiloxKey*)(hs + o_keys))[f] = make_key(seeds[f], streams[f]);
     }
-    if ((rc = pool_get(c, "b_y", (size_t)std::max(T, 1) * 8, &d_y))) return rc;
-    if (cfg->obs_times && (rc = pool_get(c, "b_ot", (size_t)std::max(T, 1) * 4, &d_ot))) return rc;
-    if ((rc = pool_get(c, "b_th", (size_t)F * nth * 8, &d_th))) return rc;
-    if ((rc = pool_get(c, "b_keys", (size_t)F * sizeof(PhiloxKey), &d_keys))) return rc;
-    void* d_lsy;
-    if ((rc = pool_get(c, "b_lsy", (size_t)F * 8, &d_lsy))) return rc;
-    if ((rc = pool_get(c, "b_ll", (size_t)F * 8, &d_ll))) return rc;
-    if ((rc = pool_get(c, "b_se", rowsSe, &d_se))) return rc;
-    if ((rc = pool_get(c, "b_ess", rowsT1, &d_ess))) return rc;
-    if ((rc = pool_get(c, "b_llh", rowsT, &d_llh))) return rc;
-    if ((rc = pool_get(c, "b_dead", (size_t)F * 4, &d_dead))) return rc;
-    if ((rc = pool_get(c, "b_flags", (size_t)F * 4, &d_flags))) return rc;
-    if ((rc = pool_get(c, "b_res", (size_t)F * 4, &d_res))) return rc;
-    std::vector<PhiloxKey> keys((size_t)F);
-    std::vector<double> lsy((size_t)F);
-    for (int f = 0; f < F; f++) { keys[f] = make_key(seeds[f], streams[f]); lsy[f] = log(thetas[(size_t)f * nth + 2]); }
-    HIPCHK(hipMemcpyAsync(d_lsy, lsy.data(), (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
-    if (T > 0) HIPCHK(hipMemcpyAsync(d_y, cfg->y, (size_t)T * 8, hipMemcpyHostToDevice, c->stream));
-    if (d_ot && T > 0) HIPCHK(hipMemcpyAsync(d_ot, cfg->obs_times, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_th, thetas, (size_t)F * nth * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_keys, keys.data(), (size_t)F * sizeof(PhiloxKey), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(d_se, 0, rowsSe, c->stream));
-    HIPCHK(hipMemsetAsync(d_ess, 0, rowsT1, c->stream));
-    HIPCHK(hipMemsetAsync(d_llh, 0, rowsT, c->stream));
+    if (T > 0) memcpy(hs + o_y, cfg->y, (size_t)T * 8);
+    for (int i = 0; i < T; i++) ((double*)(hs + o_lgy))[i] = sir ? lgamma(cfg->y[i] + 1.0) : 0.0;   // as bssm_pf_run: lgamma(y + 1) on the host
+    if (cfg->obs_times && T > 0) memcpy(hs + o_ot, cfg->obs_times, (size_t)T * 4);
+    HIPCHK(hipMemcpyAsync(d_in, hs, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(d_out, 0, out_bytes, c->stream));
+    char* di = (char*)d_in; char* dq = (char*)d_out;
+    void *d_y = di + o_y, *d_ot = cfg->obs_times ? (void*)(di + o_ot) : nullptr, *d_lgy = sir ? (void*)(di + o_lgy) : nullptr;
+    void *d_th = di + o_th, *d_lsy = di + o_lsy, *d_keys = di + o_keys;
+    void *d_ll = dq + q_ll, *d_se = dq + q_se, *d_ess = dq + q_ess, *d_llh = dq + q_llh, *d_dead = dq + q_dead, *d_flags = dq + q_flags, *d_res = dq + q_res;
     BatchArgs g;
     g.N = (int)N; g.T = T; g.resample_algorithm = cfg->resample_algorithm; g.resample_fn = cfg->resample_fn;
     g.lim = g_debug_lim > 0 ? g_debug_lim : rec_window(N);
@@ -737,19 +747,17 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipGetLastError());
-    std::vector<int> dead((size_t)F), nres((size_t)F);
-    std::vector<uint32_t> flags((size_t)F);
-    HIPCHK(hipMemcpyAsync(res->loglike, d_ll, (size_t)F * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(dead.data(), d_dead, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(flags.data(), d_flags, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(nres.data(), d_res, (size_t)F * 4, hipMemcpyDeviceToHost, c->stream));
-    if (res->state_est) HIPCHK(hipMemcpyAsync(res->state_est, d_se, rowsSe, hipMemcpyDeviceToHost, c->stream));
-    if (res->ess) HIPCHK(hipMemcpyAsync(res->ess, d_ess, rowsT1, hipMemcpyDeviceToHost, c->stream));
-    if (res->loglike_history && T > 0) HIPCHK(hipMemcpyAsync(res->loglike_history, d_llh, (size_t)F * T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hs, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
     if (d_ph) { long long h[8]; HIPCHK(hipMemcpy(h, d_ph, 64, hipMemcpyDeviceToHost)); fprintf(stderr, "k_pf_batch filter 0 cycles/observation: step %lld, weights+scan<W> %lld, apply %lld, carry/store %lld\n", h[0] / std::max(T, 1), h[1] / std::max(T, 1), h[2] / std::max(T, 1), h[3] / std::max(T, 1)); }
     if (res->device_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *res->device_ms = ms; }
+    memcpy(res->loglike, hs + q_ll, (size_t)F * 8);
+    if (res->state_est) memcpy(res->state_est, hs + q_se, rowsSe);
+    if (res->ess) memcpy(res->ess, hs + q_ess, rowsT1);
+    if (res->loglike_history && T > 0) memcpy(res->loglike_history, hs + q_llh, (size_t)F * T * 8);
+    const int* dead = (const int*)(hs + q_dead); const int* nres = (const int*)(hs + q_res);
+    const uint32_t* flags = (const uint32_t*)(hs + q_flags);
     int first_bad = BSSM_OK;
     for (int f = 0; f < F; f++) {
         if (res->ess) res->ess[(size_t)f * (T + 1)] = 1.0 / (dN * ((1.0 / dN) * (1.0 / dN)));       // :106-107
