@@ -674,8 +674,11 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN && cfg->model != BSSM_MODEL_SIR) ARGFAIL("bssm_pf_run_batch: unknown model");
     const bool sir = cfg->model == BSSM_MODEL_SIR;
     const int dim = sir ? 2 : 1;
-    if (cfg->algorithm != BSSM_BPF && cfg->algorithm != BSSM_APF) ARGFAIL("bssm_pf_run_batch: bootstrap and auxiliary filters only");
-    const bool apf = cfg->algorithm == BSSM_APF;
+    if (cfg->algorithm != BSSM_BPF && cfg->algorithm != BSSM_APF && cfg->algorithm != BSSM_RMPF) ARGFAIL("bssm_pf_run_batch: unknown algorithm");
+    const bool apf = cfg->algorithm == BSSM_APF, rmpf = cfg->algorithm == BSSM_RMPF;
+    if (rmpf && cfg->model == BSSM_MODEL_SIR) ARGFAIL("bssm_pf_run_batch: the built-in move step is defined for the scalar Gaussian-observation models only");
+    if (rmpf && !(cfg->move_sd > 0)) ARGFAIL("bssm_pf_run_batch: RMPF needs move_sd > 0");
+    if (rmpf && (cfg->z_move || cfg->u_move)) ARGFAIL("bssm_pf_run_batch: injected draws are not available in the batched path");
     if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run_batch: unknown resample_algorithm");
     if (cfg->resample_fn != BSSM_STRATIFIED && cfg->resample_fn != BSSM_SYSTEMATIC) ARGFAIL("bssm_pf_run_batch: stratified or systematic resampling only");
     if (cfg->z_init || cfg->z_trans || cfg->u_res || cfg->return_particles || cfg->return_ancestors)
@@ -690,8 +693,9 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     }
     HIPCHK(hipSetDevice(c->device));
     const double dN = (double)N;
-    double threshold = cfg->threshold;
-    if (threshold < 0) threshold = (cfg->resample_algorithm == BSSM_SIS) ? INFINITY : (cfg->resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
+    const int resample_algorithm = rmpf ? BSSM_SISR : cfg->resample_algorithm;      // RMPF forces SISR (R/resample_move_filter.R:229)
+    double threshold = rmpf ? -1.0 : cfg->threshold;
+    if (threshold < 0) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
     const int nth = cfg->n_theta;
     int rc;
     // One packed upload and one packed download per call (pinned staging): at T = 20 the filter itself takes ~0.3 ms,
@@ -725,9 +729,9 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     void *d_th = di + o_th, *d_lsy = di + o_lsy, *d_keys = di + o_keys;
     void *d_ll = dq + q_ll, *d_se = dq + q_se, *d_ess = dq + q_ess, *d_llh = dq + q_llh, *d_dead = dq + q_dead, *d_flags = dq + q_flags, *d_res = dq + q_res;
     BatchArgs g;
-    g.N = (int)N; g.T = T; g.resample_algorithm = cfg->resample_algorithm; g.resample_fn = cfg->resample_fn;
+    g.N = (int)N; g.T = T; g.resample_algorithm = resample_algorithm; g.resample_fn = cfg->resample_fn;
     g.lim = g_debug_lim > 0 ? g_debug_lim : rec_window(N);
-    g.lit_max = g_batch_lit_max;
+    g.lit_max = g_batch_lit_max; g.move_sd = cfg->move_sd;
     g.threshold = threshold; g.y = (const double*)d_y; g.obs_times = (const int*)d_ot; g.lgy = (const double*)d_lgy;
     g.theta = (const double*)d_th; g.theta_stride = nth; g.log_sy = (const double*)d_lsy; g.keys = (const PhiloxKey*)d_keys;
     g.loglike = (double*)d_ll; g.state_est = (double*)d_se; g.ess = (double*)d_ess; g.llh = (double*)d_llh;
@@ -736,15 +740,12 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     void* d_ph = nullptr;
     if (g_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 64, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 64, c->stream)); g.phase_cycles = (long long*)d_ph; }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (!apf) {
-        if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_pf_batch", (k_pf_batch<0, false>), F, NT, 0, g);
-        else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_pf_batch", (k_pf_batch<1, false>), F, NT, 0, g);
-        else LAUNCH(c, "k_pf_batch<sir>", (k_pf_batch<2, false>), F, NT, 0, g);
-    } else {
-        if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_pf_batch<apf>", (k_pf_batch<0, true>), F, NT, 0, g);
-        else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_pf_batch<apf>", (k_pf_batch<1, true>), F, NT, 0, g);
-        else LAUNCH(c, "k_pf_batch<sir,apf>", (k_pf_batch<2, true>), F, NT, 0, g);
-    }
+    const int alg = apf ? 1 : rmpf ? 2 : 0;
+#define BATCH(M, A) LAUNCH(c, "k_pf_batch", (k_pf_batch<M, A>), F, NT, 0, g)
+    if (cfg->model == BSSM_MODEL_LG) { if (alg == 0) BATCH(0, 0); else if (alg == 1) BATCH(0, 1); else BATCH(0, 2); }
+    else if (cfg->model == BSSM_MODEL_AR1SIN) { if (alg == 0) BATCH(1, 0); else if (alg == 1) BATCH(1, 1); else BATCH(1, 2); }
+    else { if (alg == 0) BATCH(2, 0); else BATCH(2, 1); }
+#undef BATCH
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(hs, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));

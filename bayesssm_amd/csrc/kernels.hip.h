@@ -1675,14 +1675,13 @@ __global__ __launch_bounds__(NT) void k_multinomial(const double* __restrict__ c
 //   proposal = particle + rnorm(1, 0, sd);  accept if log(runif(1)) < loglik(proposal) - loglik(particle).
 // Also the state-estimate partials, which the core takes AFTER the move (:237-241).
 template <int MODEL>
-__global__ __launch_bounds__(NT) void k_move(double* __restrict__ x, long long N, ModelPar par, double y, double move_sd,
-                                             const double* __restrict__ zmv, const double* __restrict__ umv,
-                                             PhiloxKey key, uint32_t call, double* __restrict__ se_part,
-                                             const DevState* __restrict__ st)
+__device__ __forceinline__ void move_block(double* sh4, const int bidx, double* __restrict__ x, long long N, const ModelPar& par, double y,
+                                           double move_sd, const double* __restrict__ zmv, const double* __restrict__ umv,
+                                           const PhiloxKey& key, uint32_t call, double* __restrict__ se_part,
+                                           const DevState* __restrict__ st)
 {
     if (st->dead) return;
-    __shared__ double sh4[4];
-    const long long base = (long long)blockIdx.x * EB;
+    const long long base = (long long)bidx * EB;
     const double invN = 1.0 / (double)N;
     double acc = 0.0;
 #pragma unroll
@@ -1701,7 +1700,17 @@ __global__ __launch_bounds__(NT) void k_move(double* __restrict__ x, long long N
         }
     }
     acc = block_sum(acc, sh4);
-    if (threadIdx.x == 0) se_part[blockIdx.x] = acc;
+    if (threadIdx.x == 0) se_part[bidx] = acc;
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(NT) void k_move(double* __restrict__ x, long long N, ModelPar par, double y, double move_sd,
+                                             const double* __restrict__ zmv, const double* __restrict__ umv,
+                                             PhiloxKey key, uint32_t call, double* __restrict__ se_part,
+                                             const DevState* __restrict__ st)
+{
+    __shared__ double sh4[4];
+    move_block<MODEL>(sh4, (int)blockIdx.x, x, N, par, y, move_sd, zmv, umv, key, call, se_part, st);
 }
 
 __global__ void k_dump_move(PhiloxKey key, uint32_t call, long long n, double* __restrict__ zout, double* __restrict__ uout)
@@ -1799,6 +1808,7 @@ __global__ void k_dump_uniforms(PhiloxKey key, uint32_t call, long long n, doubl
 struct BatchArgs {
     int N, T, resample_algorithm, resample_fn, lim;
     int lit_max;                                      // N <= lit_max: exact sums by the in-order pass (block_literal_terms)
+    double move_sd;                                   // resample-move: sd of the random-walk Metropolis proposal
     double threshold;
     const double* y; const int* obs_times;            // [T]; obs_times may be nullptr (1..T)
     const double* lgy;                                // [T] lgamma(y + 1) (SIR's Poisson observation density), or nullptr
@@ -1912,9 +1922,10 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
     }
 }
 
-template <int MODEL, bool APF>
-__global__ __launch_bounds__(NT, (MODEL == 2 || APF) ? 1 : 2) void k_pf_batch(BatchArgs g)
+template <int MODEL, int ALG>      // ALG: 0 bootstrap, 1 auxiliary, 2 resample-move
+__global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_batch(BatchArgs g)
 {
+    constexpr bool APF = (ALG == 1), RMPF = (ALG == 2);
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT + 1];
     __shared__ int Tl[EB];
@@ -2054,6 +2065,10 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || APF) ? 1 : 2) void k_pf_batch(Ba
             __syncthreads();
         }
         { double* tmp = xa; xa = xb; xb = tmp; }
+        if constexpr (RMPF && MODEL != 2) {              // move every particle, then take the state estimate (:226-241)
+            move_block<MODEL>(sm.sh4, 0, xa, N, par, yi, g.move_sd, nullptr, nullptr, key, (uint32_t)i, sep, &st);
+            __syncthreads();
+        }
         if (t == 0 && g.state_est) { for (int d = 0; d < D; d++) { double s0 = 0.0; s0 += sep[d]; g.state_est[((long long)fi * (T + 1) + i) * D + d] = s0; } }   // :237-241
         if (st.dead) break;                              // degenerate weights: the reference returns at once (:189-202)
         __syncthreads();

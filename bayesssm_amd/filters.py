@@ -122,9 +122,19 @@ def auxiliary_filter_batch(y, num_particles, init_fn, transition_fn, log_likelih
                                   _algorithm="APF", **kw)
 
 
+def resample_move_filter_batch(y, num_particles, init_fn, transition_fn, log_likelihood_fn, move_fn, thetas,
+                               seeds=0, streams=None, **kw):
+    """bootstrap_filter_batch for resample_move_filter (R/resample_move_filter.R:190-236) with the built-in random-walk
+    Metropolis move: filter k equals resample_move_filter(..., seed=seeds[k], stream=streams[k]) bit for bit."""
+    if not isinstance(move_fn, models.MoveFn):
+        raise TypeError("move_fn must be the built-in move descriptor (models.<model>.rw_move_fn(sd))")
+    return bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelihood_fn, thetas, seeds, streams,
+                                  _algorithm="RMPF", _move_sd=move_fn.sd, **kw)
+
+
 def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelihood_fn, thetas, seeds=0, streams=None,
                            obs_times=None, resample_algorithm=None, resample_fn=None, threshold=None, ctx=None,
-                           _algorithm="BPF"):
+                           _algorithm="BPF", _move_sd=0.0):
     """Many independent bootstrap filters in ONE kernel launch (one workgroup per filter, the whole T loop on chip):
     filter k runs with thetas[k] = (phi, sigma_x, sigma_y), seeds[k], streams[k] on the shared data `y`.  Each filter
     returns exactly what bootstrap_filter(..., seed=seeds[k], stream=streams[k], return_particles=False) returns.
@@ -168,7 +178,7 @@ def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelih
     ms = np.zeros(1)
     cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[_algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
                         _lib.RESAMPLE_FN[resample_fn], N, T, -1.0 if threshold is None else float(threshold),
-                        None, int(thetas.shape[1]), _ptr(y), _ptr(ot), 0, 0, None, None, None, 0, 0, 0.0, None, None)
+                        None, int(thetas.shape[1]), _ptr(y), _ptr(ot), 0, 0, None, None, None, 0, 0, float(_move_sd), None, None)
     res = _lib.PfBatchResult(_ptr(ll), _ptr(se), _ptr(ess), _ptr(llh), _ptr(ers), _ptr(nres), _ptr(status), _ptr(ms))
     _lib.check(_lib.load().bssm_pf_run_batch(ctx.handle, C.byref(cfg), F, _ptr(thetas), _ptr(seeds), _ptr(streams),
                                              C.byref(res)))

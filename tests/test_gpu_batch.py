@@ -279,3 +279,25 @@ def test_pmmh_apf_lockstep_matches_per_chain():
     for k in ("chain", "phi", "sigma_x", "sigma_y"):
         assert (a["theta_chain"][k] == c["theta_chain"][k]).all()
     assert c["_extras"]["local_chains"][0].get("batched")
+
+
+@pytest.mark.parametrize("model", ["lg", "ar1sin"])
+@pytest.mark.parametrize("N,rf", [(80, "stratified"), (900, "systematic"), (2048, "stratified")])
+def test_batch_rmpf_matches_single_bitwise(model, N, rf):
+    """resample_move_filter (R/particle_filter_core.R:226-234: resample every step, then the random-walk Metropolis
+    move of R/resample_move_filter.R:166-176, state estimate after the move) through the batched kernel."""
+    import bayesssm_amd as b
+    m = b.models.linear_gaussian() if model == "lg" else b.models.ar1_sin()
+    y = _data(14)
+    thetas = np.array([[0.8, 1.0, 0.7], [0.5, 1.2, 0.9], [0.9, 0.7, 0.4]])
+    mv = m.rw_move_fn(0.25)
+    out = b.resample_move_filter_batch(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, mv, thetas, 31, [1, 2, 3],
+                                       resample_fn=rf)
+    assert np.all(out["status"] == 0)
+    for k in range(3):
+        ref = b.resample_move_filter(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, mv, return_particles=False,
+                                     seed=31, stream=1 + k, resample_fn=rf, phi=thetas[k][0], sigma_x=thetas[k][1],
+                                     sigma_y=thetas[k][2])
+        assert out["loglike"][k] == ref["loglike"]
+        np.testing.assert_array_equal(out["ess"][k], ref["ess"])
+        np.testing.assert_array_equal(out["state_est"][k], ref["state_est"])
