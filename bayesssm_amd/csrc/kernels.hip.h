@@ -13,7 +13,10 @@
 //   k_apply<kind>         exact cum_sum -> output counts -> ancestors -> particles[indices, ]    src/resampling.cpp:28-37, R/resampling.R:40
 //   k_multinomial         inverse-CDF search on the exact cum_sum                                src/resampling.cpp:11 (distributional)
 //   k_carry               no resample at this observation: carry particles, sum(x * w)           :238
+//   k_move                resample_move_filter's random-walk Metropolis move                     :226-234
 //   k_bsum, k_plan        stand-alone resampler front end (validation, approximate block prefixes)
+//   k_pf_batch            many small filters per launch: one workgroup = one whole filter (all T observations on chip),
+//                         built from the same *_block bodies as the kernels above
 // Particles are SoA: x[dim][N] doubles; weights/log-weights [N]; ancestors int32.
 //
 // All arithmetic that the reference defines is done in fp64 with contraction
@@ -31,7 +34,6 @@ constexpr int NT = 256;          // threads per workgroup (4 waves)
 constexpr int EL = 8;            // terms per thread in the scan kernels
 constexpr int EB = NT * EL;      // 2048 terms per workgroup
 constexpr int MAXB = 2048;       // max scan workgroups  => N <= 2^22 per filter
-constexpr int MAXG = 64;         // max groups in k_resolve
 
 constexpr int MODE_W = 0;        // terms are the weights themselves        (total = sum(w))
 constexpr int MODE_P = 1;        // terms are prob = w / total              (cum = cumsum(prob))
@@ -193,22 +195,6 @@ __device__ __forceinline__ double block_excl_scan(double x, double* sh4)
     double pre = 0.0;
     for (int i = 0; i < wave; i++) pre += sh4[i];
     return pre + exc;
-}
-
-// Reduce the per-block (max, sumexp) partials to the global pair; every
-// thread of every calling block gets the same value (same order everywhere).
-template <int NW = NT / 64>
-__device__ void reduce_lse_partials(const double* pm, const double* ps, int nb, double* sh, double& M, double& S)
-{
-    double m = -INFINITY;
-    for (int i = threadIdx.x; i < nb; i += NW * 64) m = fmax(m, pm[i]);
-    M = block_max_n<NW>(m, sh);
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nb; i += NW * 64) {
-        const double mb = pm[i];
-        if (mb > -INFINITY) s += ps[i] * exp(mb - M);
-    }
-    S = block_sum_n<NW>(s, sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -628,11 +614,10 @@ struct SegSmem {
     WalkFn wf[MAXBND + 1];           // the boundary chain as data (walk_chain)
     uint64_t sseq[MAXBND + 1];       // its state sequence
     uint64_t seg_start[MAXBND + 1];
-    uint64_t lane_exit[4];       // exit state of the last lane of each wave (only [3] is used)
     long long red_min[4][2], red_max[4][2];
     uint64_t seg1_base;
     uint64_t segbase[MAXBND + 1]; int smin[MAXBND + 1]; int smax[MAXBND + 1];
-    int nb; int fail; int first_bnd; int first_kind;
+    int nb; int fail; int first_bnd;
     double sh4[16];
     double bcast;
 };
@@ -1112,9 +1097,9 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         return;
     }
     // validity windows of segment 0 (lanes before the first boundary) and of the last segment when nb == 1
-    if (t == 0) { sm.first_bnd = NT; sm.first_kind = REC_PURE; }
+    if (t == 0) sm.first_bnd = NT;
     __syncthreads();
-    if (bs.isb && bs.seg == 0) { sm.first_bnd = t; sm.first_kind = bs.leaf.kind; }
+    if (bs.isb && bs.seg == 0) sm.first_bnd = t;
     __syncthreads();
     const int fb = sm.first_bnd;
     if (bs.nb >= 1 && t == fb + 1) sm.seg1_base = bs.leaf.base;
