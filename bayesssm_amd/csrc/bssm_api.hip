@@ -738,7 +738,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     g.dead = (int*)d_dead; g.flags = (uint32_t*)d_flags; g.res_calls = (int*)d_res;
     g.phase_cycles = nullptr;
     void* d_ph = nullptr;
-    if (g_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 64, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 64, c->stream)); g.phase_cycles = (long long*)d_ph; }
+    if (g_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 40 * 8, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 40 * 8, c->stream)); g.phase_cycles = (long long*)d_ph; }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     const int alg = apf ? 1 : rmpf ? 2 : 0;
 #define BATCH(M, A) LAUNCH(c, "k_pf_batch", (k_pf_batch<M, A>), F, NT, 0, g)
@@ -751,7 +751,10 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     HIPCHK(hipMemcpyAsync(hs, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
-    if (d_ph) { long long h[8]; HIPCHK(hipMemcpy(h, d_ph, 64, hipMemcpyDeviceToHost)); fprintf(stderr, "k_pf_batch filter 0 cycles/observation: step %lld, weights+scan<W> %lld, apply %lld, carry/store %lld\n", h[0] / std::max(T, 1), h[1] / std::max(T, 1), h[2] / std::max(T, 1), h[3] / std::max(T, 1)); }
+    if (d_ph) { long long h[40]; HIPCHK(hipMemcpy(h, d_ph, 40 * 8, hipMemcpyDeviceToHost));
+        const long long* w2 = h + 8; const long long* a3 = h + 24;
+        fprintf(stderr, "   last observation, weights block: start->prologue %lld, ->weights %lld, ->terms ready %lld;  apply block: start->loaded %lld, ->in-order/resolve %lld, ->counts %lld, ->expanded %lld, ->state est %lld\n",
+                w2[8] - w2[4], w2[9] - w2[8], w2[1] - w2[9], a3[1] - a3[0], a3[3] - a3[1], a3[4] - a3[3], a3[5] - a3[4], a3[6] - a3[5]); fprintf(stderr, "k_pf_batch filter 0 cycles/observation: step %lld, weights+scan<W> %lld, apply %lld, carry/store %lld\n", h[0] / std::max(T, 1), h[1] / std::max(T, 1), h[2] / std::max(T, 1), h[3] / std::max(T, 1)); }
     if (res->device_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *res->device_ms = ms; }
     memcpy(res->loglike, hs + q_ll, (size_t)F * 8);
     if (res->state_est) memcpy(res->state_est, hs + q_se, rowsSe);

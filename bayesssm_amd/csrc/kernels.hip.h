@@ -1802,7 +1802,7 @@ struct BatchArgs {
     const PhiloxKey* keys;                            // [F]
     double* loglike; double* state_est; double* ess; double* llh;    // [F], [F][T+1][D], [F][T+1], [F][T]
     int* dead; uint32_t* flags; int* res_calls;       // [F]
-    long long* phase_cycles;                          // dev tool: [8] cycles per phase summed over filter 0's observations, or nullptr
+    long long* phase_cycles;                          // dev tool: [8] cycles per phase summed over filter 0's observations + [2][16] stage stamps, or nullptr
 };
 
 // k_step<MODEL, TRANS, WEIGHT, false> for one block of up to EB particles, by NT threads: thread t plays the threads
@@ -1942,7 +1942,8 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
     const bool lit = g.N <= g.lit_max;      // few terms: the in-order pass beats the record machinery's fixed latency
     if (t == 0) {
         st.loglike = 0.0; st.lse_max = 0.0; st.lse_sum = 0.0; st.ess = 0.0; st.total_bits = 0;
-        st.do_resample = 0; st.dead = 0; st.flags = 0; st.res_calls = 0; st.cur_call = 0; st.debug_stop = 0;
+        st.do_resample = 0; st.dead = 0; st.flags = 0; st.res_calls = 0; st.cur_call = 0;
+        st.debug_stop = (g.phase_cycles != nullptr && fi == 0) ? 99 : 0;      // dev tool: stage stamps of the last observation
         st.stat_hard_blocks = 0; st.stat_serial_walks = 0; st.stat_literal_terms = 0;
         sep[0] = 0.0; sep[1] = 0.0;
     }
@@ -2059,7 +2060,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         __syncthreads();
         PH(3)
     }
-    if (prof) { for (int k = 0; k < 6; k++) g.phase_cycles[k] = ph[k]; }
+    if (prof) { for (int k = 0; k < 6; k++) g.phase_cycles[k] = ph[k]; for (int r = 0; r < 2; r++) for (int k = 0; k < 16; k++) g.phase_cycles[8 + 16 * r + k] = st.stamps[2 + r][k]; }
 #undef PH
     if (t == 0) { g.loglike[fi] = st.loglike; g.dead[fi] = st.dead; g.flags[fi] = st.flags; g.res_calls[fi] = st.res_calls; }
 }

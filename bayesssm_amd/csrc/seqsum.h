@@ -273,9 +273,10 @@ BSSM_HD int32_t count_le_systematic(double c, int32_t n, double U)
     double g = c * dn - U;
     {   // Fast path.  u_i = (i+U)/n (1+e), |e| <= 2^-52, and g = c n - U carries an error <= n 2^-52, so
         // "u_i <= c" is decided by "i <= g" whenever g is further than n 2^-49 from an integer.
+        // That covers every i in [0, n), so the count is floor(g) + 1 clamped to [0, n] -- also at the two ends.
         const double delta = dn * 0x1.0p-49;
         const double fl = floor(g), fr = g - fl;
-        if (g > delta && g < dn - 1.0 && fr > delta && fr < 1.0 - delta) return (int32_t)fl + 1;
+        if (fr > delta && fr < 1.0 - delta) return fl < 0.0 ? 0 : (fl >= dn ? n : (int32_t)fl + 1);
     }
     int64_t t = (g < 0) ? 0 : (g >= dn ? (int64_t)n : (int64_t)g + 1);
     if (t > n) t = n;
@@ -295,7 +296,9 @@ BSSM_HD int32_t count_le_stratified(double c, int32_t n, const UF& U)
         // only output floor(g) needs the reference expression itself.
         const double delta = dn * 0x1.0p-49;
         const double fl = floor(g), fr = g - fl;
-        if (g > 1.0 && g < dn - 1.0 && fr > delta && fr < 1.0 - delta) {
+        if (fr > delta && fr < 1.0 - delta) {
+            if (fl < 0.0) return 0;
+            if (fl >= dn) return n;
             const int32_t i0 = (int32_t)fl;
             return i0 + ((((double)i0 + U(i0)) / dn) > c ? 0 : 1);
         }
