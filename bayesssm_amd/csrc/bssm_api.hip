@@ -5,6 +5,7 @@
 //   bssm_pmmh_chain  = chain_result's MH loop               R/pmmh.R:403-415,422-500
 // One context = one GPU + one stream; device memory is owned by the context.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -208,23 +209,25 @@ extern "C" int bssm_ctx_get_profile(bssm_ctx* c, int max_entries, const char** n
     return k;
 }
 
-// ---- launch helper: optional per-kernel-class HIP-event timing -------------------
-struct LaunchScope {
-    bssm_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
-    LaunchScope(bssm_ctx* c_, const char* n) : c(c_), name(n)
-    {
-        if (!c->profile) return;
-        auto get = [&]() { hipEvent_t e; if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
-        a = get(); b = get();
-        (void)hipEventRecord(a, c->stream);
-    }
-    ~LaunchScope()
-    {
-        if (!c->profile) return;
-        (void)hipEventRecord(b, c->stream);
-        c->prof_pending.push_back({name, {a, b}});
-    }
-};
+// ---- launch helper: optional per-kernel-class timing ------------------------------------------
+// Profile mode hands the launch a start and a stop event (hipExtLaunchKernelGGL): they receive the begin / end
+// timestamps of the kernel's own dispatch, i.e. the duration rocprofv3 --kernel-trace reports.  (A pair of
+// hipEventRecord calls around the launch would also time the dispatch of the launch, ~2.5 us here.)
+static hipEvent_t prof_event(bssm_ctx* c)
+{
+    hipEvent_t e = nullptr;
+    if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e);
+    return e;
+}
+#define LAUNCH(c, name, kern, grid, block, shmem, ...)                                                              \
+    do {                                                                                                              \
+        if ((c)->profile) {                                                                                           \
+            hipEvent_t ea__ = prof_event(c), eb__ = prof_event(c);                                                    \
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, (c)->stream, ea__, eb__, 0, __VA_ARGS__);     \
+            (c)->prof_pending.push_back({name, {ea__, eb__}});                                                        \
+        } else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, (c)->stream, __VA_ARGS__);                    \
+    } while (0)
+
 static void prof_collect(bssm_ctx* c)
 {
     for (auto& p : c->prof_pending) {
@@ -236,9 +239,6 @@ static void prof_collect(bssm_ctx* c)
     }
     c->prof_pending.clear();
 }
-#define LAUNCH(c, name, kern, grid, block, shmem, ...)                                      \
-    do { LaunchScope ls__(c, name); hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, (c)->stream, __VA_ARGS__); } while (0)
-
 static PhiloxKey make_key(unsigned long long seed, unsigned long long stream)
 {
     PhiloxKey k; k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32);

@@ -156,7 +156,8 @@ def main():
                       "read_only_frac": SWEEP_READ_BYTES * N * T / (per_run_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if not args.no_profile:
-            # one extra, un-timed pass with HIP events around every launch: per-kernel-class durations
+            # one extra, un-timed pass; every launch carries a start/stop event pair (hipExtLaunchKernelGGL) that receives
+            # the begin/end timestamps of the kernel's own dispatch: per-kernel-class durations, as rocprofv3 reports them
             ctx.set_profile(True)
             run(999999)
             prof = ctx.get_profile()
