@@ -69,7 +69,8 @@ struct DevState {
     long long stamps[4][16];      // dev tool: clock64() at stage boundaries (debug_stop == 99)
 };
 
-#define BSSM_STAMP(st, dbg, row, col, cond) do { if ((dbg) == 99 && (cond)) (st)->stamps[row][col] = clock64(); } while (0)
+// dev tool: debug_stop 99 stamps a typical block (block 100 of a large grid), 98 the head block (block 0)
+#define BSSM_STAMP(st, dbg, row, col, cond) do { if (((dbg) == 99 || (dbg) == 98) && (cond)) (st)->stamps[row][col] = clock64(); } while (0)
 
 // ---------------------------------------------------------------------------
 // small block-level helpers (wave64 shuffles, then LDS across the 4 waves)
@@ -957,7 +958,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
     const double a_in_pre = FROM_LW ? 0.0 : ain[bidx];
     if (s_dead || s_flags) return;
     if (!FROM_LW && !s_do) return;
-    const bool stamper = (t == 0 && bidx == (nblk > 100 ? 100 : 0));
+    const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0));
     BSSM_STAMP(st, dbg, 2, FROM_LW ? 4 : 0, stamper);
     double v[EL];
     double a_in;
@@ -1497,7 +1498,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
     us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
     us.key = a.key; us.call = (uint32_t)call;
     const double Usys = (KIND == 1) ? us(0) : 0.0;
-    const bool stamper = (t == 0 && bidx == (nblk > 100 ? 100 : 0));
+    const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0));
     BSSM_STAMP(st, dbg, 3, 0, stamper);
 #pragma unroll
     for (int k = 0; k < EL; k++) v[k] = v[k] / total;                  // prob = weights / total (src/resampling.cpp:24,51)
