@@ -1463,9 +1463,11 @@ struct ApplyArgs {
     double* se_part;              // [B][dim] partial sums of x * (1/N) after resampling, or nullptr
 };
 
+constexpr int CAPX = 3072;       // outputs a block can stage in LDS for the coalesced store (it owns ~EB of them)
+
 template <int KIND, bool LIT = false>
 __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
-                                            const ApplyArgs& a, DevState* st)
+                                            const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [CAPX] or nullptr */)
 {
     const int t = threadIdx.x;
     const long long b0 = (long long)bidx * EB;
@@ -1565,20 +1567,44 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
     }
     const int any_big = __syncthreads_or(maxcnt > 64);
     if (!any_big) {
+        // Scattered 8-byte stores cost the CU one address per lane (64 cache lines per wave instruction): with the
+        // particles going straight to HBM that address traffic, not the bytes, bounded this stage.  Plain case
+        // (scalar state, nothing else to carry): scatter into LDS, then store the block's output range coalesced.
+        const bool stage = (lx != nullptr) && a.xdst && !anc && a.dim == 1 && !a.auxdst && (Te - Tb) <= CAPX;
         int p = tprev;
+        if (stage) {
 #pragma unroll
-        for (int k = 0; k < EL; k++) {
-            const int T = Tk[k];
-            const long long src = b0 + (long long)t * EL + k;
-            for (int i = p; i < T; i++) {
-                if (anc) anc[i] = (int)(src + 1);                    // 1-based (src/resampling.cpp:36,62)
-                if (a.xdst) {
-                    a.xdst[i] = xs0[k]; acc0 += xs0[k] * invN;
-                    if (a.dim > 1) { a.xdst[a.xstride + i] = xs1[k]; acc1 += xs1[k] * invN; }
-                }
-                if (a.auxdst) a.auxdst[i] = axs[k];
+            for (int k = 0; k < EL; k++) {
+                const int T = Tk[k];
+                for (int i = p; i < T; i++) lx[i - Tb] = xs0[k];
+                p = T;
             }
-            p = T;
+        } else {
+#pragma unroll
+            for (int k = 0; k < EL; k++) {
+                const int T = Tk[k];
+                const long long src = b0 + (long long)t * EL + k;
+                for (int i = p; i < T; i++) {
+                    if (anc) anc[i] = (int)(src + 1);                    // 1-based (src/resampling.cpp:36,62)
+                    if (a.xdst) {
+                        a.xdst[i] = xs0[k];
+                        if (a.dim > 1) a.xdst[a.xstride + i] = xs1[k];
+                    }
+                    if (a.auxdst) a.auxdst[i] = axs[k];
+                }
+                p = T;
+            }
+        }
+        // the state estimate sums the block's outputs in output order, strided over the lanes (every path does)
+        if (a.xdst) {
+            __syncthreads();
+            for (int i = Tb + t; i < Te; i += NT) {
+                if (stage) { const double x0 = lx[i - Tb]; a.xdst[i] = x0; acc0 += x0 * invN; }
+                else {
+                    acc0 += a.xdst[i] * invN;
+                    if (a.dim > 1) acc1 += a.xdst[a.xstride + i] * invN;
+                }
+            }
         }
     } else {
         for (int i = Tb + t; i < Te; i += NT) {
@@ -1615,7 +1641,8 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     __shared__ uint64_t tin[NT];
     __shared__ int Tl[EB];
     __shared__ int Tbegin;
-    apply_block<KIND>(sm, tin, Tl, Tbegin, (int)blockIdx.x, (int)gridDim.x, a, st);
+    __shared__ double lx[CAPX];
+    apply_block<KIND>(sm, tin, Tl, Tbegin, (int)blockIdx.x, (int)gridDim.x, a, st, lx);
 }
 
 // multinomial: inverse CDF on the exact cum_sum (distributional parity only)
