@@ -138,6 +138,8 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<MODE_W>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXB * (int)sizeof(BlockRec));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<MODE_P>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXB * (int)sizeof(BlockRec));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
     if (e != hipSuccess) {
         g_err = std::string("bssm_ctx_create: ") + hipGetErrorString(e);
         bssm_ctx_destroy(c);
@@ -279,8 +281,11 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     a.cum_out = (r.kind == BSSM_MULTINOMIAL) ? (r.d_cum ? r.d_cum : c->cum) : r.d_cum;
     a.xsrc = r.xsrc; a.xdst = r.xdst; a.dim = r.dim; a.xstride = r.xstride;
     a.auxsrc = r.auxsrc; a.auxdst = r.auxdst; a.se_part = r.se_part;
-    if (r.kind == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>", k_apply<1>, B, NT, 0, a, c->st);
-    else if (r.kind == BSSM_STRATIFIED) LAUNCH(c, "k_apply<stratified>", k_apply<0>, B, NT, 0, a, c->st);
+    // LDS staging for the coalesced particle store: one array per thing carried to the outputs
+    a.nstage = (r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
+    const size_t xshm = (size_t)a.nstage * CAPX * sizeof(double);
+    if (r.kind == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>", k_apply<1>, B, NT, xshm, a, c->st);
+    else if (r.kind == BSSM_STRATIFIED) LAUNCH(c, "k_apply<stratified>", k_apply<0>, B, NT, xshm, a, c->st);
     else {
         LAUNCH(c, "k_apply<cum>", k_apply<2>, B, NT, 0, a, c->st);
         const int Bo = (int)(((long long)r.n + EB - 1) / EB);

@@ -1461,13 +1461,14 @@ struct ApplyArgs {
     const double* xsrc; double* xdst; int dim; long long xstride;   // gather particles[indices, ]
     const double* auxsrc; double* auxdst;                            // gather aux_log_weights[ancestors]
     double* se_part;              // [B][dim] partial sums of x * (1/N) after resampling, or nullptr
+    int nstage;                   // k_apply: LDS staging arrays provided by the launch (0..3 x CAPX doubles)
 };
 
 constexpr int CAPX = 3072;       // outputs a block can stage in LDS for the coalesced store (it owns ~EB of them)
 
 template <int KIND, bool LIT = false>
 __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
-                                            const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [CAPX] or nullptr */)
+                                            const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [nstage][CAPX] or nullptr */, const int nstage = 0)
 {
     const int t = threadIdx.x;
     const long long b0 = (long long)bidx * EB;
@@ -1570,13 +1571,21 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         // Scattered 8-byte stores cost the CU one address per lane (64 cache lines per wave instruction): with the
         // particles going straight to HBM that address traffic, not the bytes, bounded this stage.  Plain case
         // (scalar state, nothing else to carry): scatter into LDS, then store the block's output range coalesced.
-        const bool stage = (lx != nullptr) && a.xdst && !anc && a.dim == 1 && !a.auxdst && (Te - Tb) <= CAPX;
+        // (the second state component and the auxiliary log-weights are staged the same way when the launch provides room)
+        const int need = (a.dim > 1 ? 2 : 1) + (a.auxdst ? 1 : 0);
+        const bool stage = (lx != nullptr) && a.xdst && !anc && need <= nstage && (Te - Tb) <= CAPX;
+        double* lx1 = lx + CAPX;                                   // second state component
+        double* lxa = lx + (a.dim > 1 ? 2 : 1) * CAPX;             // auxiliary log-weights
         int p = tprev;
         if (stage) {
 #pragma unroll
             for (int k = 0; k < EL; k++) {
                 const int T = Tk[k];
-                for (int i = p; i < T; i++) lx[i - Tb] = xs0[k];
+                for (int i = p; i < T; i++) {
+                    lx[i - Tb] = xs0[k];
+                    if (a.dim > 1) lx1[i - Tb] = xs1[k];
+                    if (a.auxdst) lxa[i - Tb] = axs[k];
+                }
                 p = T;
             }
         } else {
@@ -1599,8 +1608,11 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         if (a.xdst) {
             __syncthreads();
             for (int i = Tb + t; i < Te; i += NT) {
-                if (stage) { const double x0 = lx[i - Tb]; a.xdst[i] = x0; acc0 += x0 * invN; }
-                else {
+                if (stage) {
+                    const double x0 = lx[i - Tb]; a.xdst[i] = x0; acc0 += x0 * invN;
+                    if (a.dim > 1) { const double x1 = lx1[i - Tb]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
+                    if (a.auxdst) a.auxdst[i] = lxa[i - Tb];
+                } else {
                     acc0 += a.xdst[i] * invN;
                     if (a.dim > 1) acc1 += a.xdst[a.xstride + i] * invN;
                 }
@@ -1641,8 +1653,8 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
     __shared__ uint64_t tin[NT];
     __shared__ int Tl[EB];
     __shared__ int Tbegin;
-    __shared__ double lx[CAPX];
-    apply_block<KIND>(sm, tin, Tl, Tbegin, (int)blockIdx.x, (int)gridDim.x, a, st, lx);
+    extern __shared__ __attribute__((aligned(16))) double lx[];      // [a.nstage][CAPX], sized by the launch
+    apply_block<KIND>(sm, tin, Tl, Tbegin, (int)blockIdx.x, (int)gridDim.x, a, st, a.nstage ? lx : nullptr, a.nstage);
 }
 
 // multinomial: inverse CDF on the exact cum_sum (distributional parity only)
@@ -2026,7 +2038,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             ApplyArgs aa;
             aa.w = LW; aa.nw = N; aa.ain_p = &ainp1; aa.cin = &cin1; aa.lim = g.lim; aa.n = (int)N;
             aa.u_base = nullptr; aa.u_stride = 0; aa.key = key; aa.anc_out = nullptr; aa.anc_stride = 0; aa.cum_out = nullptr;
-            aa.xsrc = xa; aa.xdst = xb; aa.dim = D; aa.xstride = N; aa.auxsrc = AUXLW; aa.auxdst = AUXG; aa.se_part = nullptr;
+            aa.xsrc = xa; aa.xdst = xb; aa.dim = D; aa.xstride = N; aa.auxsrc = AUXLW; aa.auxdst = AUXG; aa.se_part = nullptr; aa.nstage = 0;
             if (g.resample_fn == 1) {
                 if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, aa, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, aa, &st);
             } else {
@@ -2066,7 +2078,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         ApplyArgs a;
         a.w = LW; a.nw = N; a.ain_p = &ainp1; a.cin = &cin1; a.lim = g.lim; a.n = (int)N;
         a.u_base = nullptr; a.u_stride = 0; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;
-        a.xsrc = xa; a.xdst = xb; a.dim = D; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = sep;
+        a.xsrc = xa; a.xdst = xb; a.dim = D; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = sep; a.nstage = 0;
         if (g.resample_fn == 1) {                                                         // systematic
             if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
         } else {                                                                          // stratified
