@@ -181,6 +181,8 @@ static int g_debug_stop = 0;
 extern "C" void bssm_debug_set_stop(int stage) { g_debug_stop = stage; }
 // Test aid: override the validity window of the scan records (ulps).  A tiny window makes the per-lane
 // verification fail almost everywhere, which drives the literal fallbacks of the real kernels.
+static int g_stage = 1;                 // dev knob: LDS staging of k_apply's particle stores
+extern "C" void bssm_debug_set_stage(int on) { g_stage = on; }
 static int g_debug_lim = 0;
 extern "C" void bssm_debug_set_window(int lim) { g_debug_lim = lim; }
 __global__ void k_set_debug(DevState* st, int v) { st->debug_stop = v; }
@@ -282,7 +284,7 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     a.xsrc = r.xsrc; a.xdst = r.xdst; a.dim = r.dim; a.xstride = r.xstride;
     a.auxsrc = r.auxsrc; a.auxdst = r.auxdst; a.se_part = r.se_part;
     // LDS staging for the coalesced particle store: one array per thing carried to the outputs
-    a.nstage = (r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
+    a.nstage = (g_stage && r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
     const size_t xshm = (size_t)a.nstage * CAPX * sizeof(double);
     if (r.kind == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>", k_apply<1>, B, NT, xshm, a, c->st);
     else if (r.kind == BSSM_STRATIFIED) LAUNCH(c, "k_apply<stratified>", k_apply<0>, B, NT, xshm, a, c->st);
