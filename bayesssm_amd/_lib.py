@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbayesssm_amd.so")
+# (BAYESSSM_AMD_LIB: load another build of the same library -- used by dev A/B runs of two builds on one GPU box)
+LIB_PATH = os.environ.get("BAYESSSM_AMD_LIB") or os.path.join(_HERE, "libbayesssm_amd.so")
 
 OK, ERR_NEGATIVE, ERR_ZERO_SUM, ERR_LENGTH, ERR_ARG, ERR_HIP, ERR_CAPACITY = range(7)
 MODEL = {"lg": 0, "ar1sin": 1, "sir": 2}

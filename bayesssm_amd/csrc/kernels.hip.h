@@ -743,7 +743,7 @@ __device__ __forceinline__ double term_at(const double* __restrict__ w, long lon
 
 // literal left-to-right run over terms [j0, j1) from exact state `in`
 template <int MODE>
-__device__ uint64_t literal_run(const double* __restrict__ w, long long nw, double total, long long j0, long long j1, uint64_t in)
+__device__ __attribute__((noinline)) uint64_t literal_run(const double* __restrict__ w, long long nw, double total, long long j0, long long j1, uint64_t in)
 {
     double c = b2d(in);
     for (long long j = j0; j < j1; j++) c = c + term_at<MODE>(w, nw, total, j);
@@ -841,7 +841,7 @@ __device__ __forceinline__ bool block_resolve(SegSmem& sm, const BlockScan& bs, 
 
 // Literal fallback: thread 0 runs the whole block in order and records each lane's incoming state.
 template <int MODE>
-__device__ __forceinline__ void block_literal(uint64_t* tin /* LDS [NT] */, uint64_t cin, const double* __restrict__ w,
+__device__ __attribute__((noinline)) void block_literal(uint64_t* tin /* LDS [NT] */, uint64_t cin, const double* __restrict__ w,
                                               long long nw, double total, long long b0, DevState* st)
 {
     if (threadIdx.x == 0) {
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
 // run of PURE blocks is a PURE chunk, anything else is a boundary chunk.
 // ---------------------------------------------------------------------------
 template <int MODE>
-__device__ uint64_t block_out_exact(const BlockRec& br, const SideList* __restrict__ side, const double* __restrict__ w,
+__device__ __attribute__((noinline)) uint64_t block_out_exact(const BlockRec& br, const SideList* __restrict__ side, const double* __restrict__ w,
                                     long long nw, double total, long long b, uint64_t in, long long& lit)
 {
     bool ok = true;

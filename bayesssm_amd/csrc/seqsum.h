@@ -266,6 +266,22 @@ BSSM_HD uint64_t run_literal(const double* v, int L, int vs, uint64_t in)
 // (and the last element owns everything up to n).
 // ---------------------------------------------------------------------------
 
+// the reference's own predicate around the candidate (rare: c n - U within n 2^-49 of an integer); kept out of line so
+// that the callers' hot instruction stream stays short
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline))
+#endif
+inline int32_t count_le_systematic_exact(double c, int32_t n, double U, double g)
+{
+    const double dn = (double)n;
+    int64_t t = (g < 0) ? 0 : (g >= dn ? (int64_t)n : (int64_t)g + 1);
+    if (t > n) t = n;
+    // pred(i): u_i <= c, true for small i, false for large i
+    while (t < n && !((((double)t + U) / dn) > c)) t++;
+    while (t > 0 && ((((double)(t - 1) + U) / dn) > c)) t--;
+    return (int32_t)t;
+}
+
 // systematic: U scalar
 BSSM_HD int32_t count_le_systematic(double c, int32_t n, double U)
 {
@@ -278,12 +294,7 @@ BSSM_HD int32_t count_le_systematic(double c, int32_t n, double U)
         const double fl = floor(g), fr = g - fl;
         if (fr > delta && fr < 1.0 - delta) return fl < 0.0 ? 0 : (fl >= dn ? n : (int32_t)fl + 1);
     }
-    int64_t t = (g < 0) ? 0 : (g >= dn ? (int64_t)n : (int64_t)g + 1);
-    if (t > n) t = n;
-    // pred(i): u_i <= c, true for small i, false for large i
-    while (t < n && !((((double)t + U) / dn) > c)) t++;
-    while (t > 0 && ((((double)(t - 1) + U) / dn) > c)) t--;
-    return (int32_t)t;
+    return count_le_systematic_exact(c, n, U, g);
 }
 
 // stratified: U(i) per output (array in parity mode, generator otherwise)
