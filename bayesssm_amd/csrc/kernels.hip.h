@@ -1199,8 +1199,8 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
 // run of PURE blocks is a PURE chunk, anything else is a boundary chunk.
 // ---------------------------------------------------------------------------
 template <int MODE>
-__device__ __attribute__((noinline)) uint64_t block_out_exact(const BlockRec& br, const SideList* __restrict__ side, const double* __restrict__ w,
-                                    long long nw, double total, long long b, uint64_t in, long long& lit)
+__device__ __forceinline__ uint64_t block_out_exact_body(const BlockRec& br, const SideList* __restrict__ side, const double* __restrict__ w,
+                                                         long long nw, double total, long long b, uint64_t in, long long& lit)
 {
     bool ok = true;
     uint64_t o = rec_step(br.prefix, in, ok);
@@ -1241,6 +1241,26 @@ __device__ __attribute__((noinline)) uint64_t block_out_exact(const BlockRec& br
     if (j0 >= e1) return o;
     lit += e1 - j0;
     return literal_run<MODE>(w, nw, total, j0, e1, o);
+}
+
+// Out of line (rare, and the resolver's hot instruction stream should stay short); results by value so that the
+// caller's counters stay in registers.
+struct OutLit { uint64_t out; long long lit; };
+template <int MODE>
+__device__ __attribute__((noinline)) OutLit block_out_exact_nl(const BlockRec* br, const SideList* side, const double* w,
+                                                               long long nw, double total, long long b, uint64_t in)
+{
+    OutLit r; r.lit = 0;
+    r.out = block_out_exact_body<MODE>(*br, side, w, nw, total, b, in, r.lit);
+    return r;
+}
+template <int MODE>
+__device__ __forceinline__ uint64_t block_out_exact(const BlockRec& br, const SideList* __restrict__ side, const double* __restrict__ w,
+                                                    long long nw, double total, long long b, uint64_t in, long long& lit)
+{
+    const OutLit r = block_out_exact_nl<MODE>(&br, side, w, nw, total, b, in);
+    lit += r.lit;
+    return r.out;
 }
 
 constexpr int NTR = 1024;        // threads of the single resolve workgroup (16 waves)
@@ -1464,6 +1484,34 @@ struct ApplyArgs {
     int nstage;                   // k_apply: LDS staging arrays provided by the launch (0..3 x CAPX doubles)
 };
 
+// Expansion when an element owns more than 64 outputs (degenerate weights: a few particles own almost everything): all
+// lanes share the work through a binary search in the counts.  Rare: out of line.
+// (arguments and results by value: taking the caller's accumulators or its argument block by reference would push them
+// into scratch memory on the hot path as well)
+__device__ __attribute__((noinline)) double2 expand_by_search(const int* Tl, int* anc, const double* xsrc, double* xdst, int dim, long long xstride,
+                                                              const double* auxsrc, double* auxdst, long long b0, int Tb, int Te, double invN)
+{
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int i = Tb + (int)threadIdx.x; i < Te; i += NT) {
+        // first local index whose count exceeds i
+        int lo = 0, hi = EB - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (Tl[mid] > i) hi = mid; else lo = mid + 1;
+        }
+        const long long src = b0 + lo;
+        if (anc) anc[i] = (int)(src + 1);
+        if (xdst) {
+            const double x0 = xsrc[src];
+            xdst[i] = x0; acc0 += x0 * invN;
+            if (dim > 1) { const double x1 = xsrc[xstride + src]; xdst[xstride + i] = x1; acc1 += x1 * invN; }
+        }
+        if (auxdst) auxdst[i] = auxsrc[src];
+    }
+    double2 r; r.x = acc0; r.y = acc1;
+    return r;
+}
+
 constexpr int CAPX = 3072;       // outputs a block can stage in LDS for the coalesced store (it owns ~EB of them)
 
 template <int KIND, bool LIT = false>
@@ -1619,22 +1667,8 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
             }
         }
     } else {
-        for (int i = Tb + t; i < Te; i += NT) {
-            // first local index whose count exceeds i
-            int lo = 0, hi = EB - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (Tl[mid] > i) hi = mid; else lo = mid + 1;
-            }
-            const long long src = b0 + lo;
-            if (anc) anc[i] = (int)(src + 1);
-            if (a.xdst) {
-                const double x0 = a.xsrc[src];
-                a.xdst[i] = x0; acc0 += x0 * invN;
-                if (a.dim > 1) { const double x1 = a.xsrc[a.xstride + src]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
-            }
-            if (a.auxdst) a.auxdst[i] = a.auxsrc[src];
-        }
+        const double2 r = expand_by_search(Tl, anc, a.xsrc, a.xdst, a.dim, a.xstride, a.auxsrc, a.auxdst, b0, Tb, Te, invN);
+        acc0 = r.x; acc1 = r.y;
     }
     BSSM_STAMP(st, dbg, 3, 5, stamper);
     if (a.se_part) {

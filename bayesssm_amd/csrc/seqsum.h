@@ -297,6 +297,20 @@ BSSM_HD int32_t count_le_systematic(double c, int32_t n, double U)
     return count_le_systematic_exact(c, n, U, g);
 }
 
+template <class UF>
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline))
+#endif
+inline int32_t count_le_stratified_exact(double c, int32_t n, const UF& U, double g)
+{
+    const double dn = (double)n;
+    int64_t t = (g < 0) ? 0 : (g >= dn ? (int64_t)n : (int64_t)g);
+    if (t > n) t = n;
+    while (t < n && !((((double)t + U((int32_t)t)) / dn) > c)) t++;
+    while (t > 0 && ((((double)(t - 1) + U((int32_t)(t - 1))) / dn) > c)) t--;
+    return (int32_t)t;
+}
+
 // stratified: U(i) per output (array in parity mode, generator otherwise)
 template <class UF>
 BSSM_HD int32_t count_le_stratified(double c, int32_t n, const UF& U)
@@ -314,11 +328,7 @@ BSSM_HD int32_t count_le_stratified(double c, int32_t n, const UF& U)
             return i0 + ((((double)i0 + U(i0)) / dn) > c ? 0 : 1);
         }
     }
-    int64_t t = (g < 0) ? 0 : (g >= dn ? (int64_t)n : (int64_t)g);
-    if (t > n) t = n;
-    while (t < n && !((((double)t + U((int32_t)t)) / dn) > c)) t++;
-    while (t > 0 && ((((double)(t - 1) + U((int32_t)(t - 1))) / dn) > c)) t--;
-    return (int32_t)t;
+    return count_le_stratified_exact(c, n, U, g);
 }
 
 struct UniformArray {
