@@ -111,6 +111,11 @@ def main():
                                   resample_algorithm="SISR", resample_fn=args.resample_fn, return_particles=False,
                                   seed=1405, stream=stream, ctx=ctx, phi=theta[0], sigma_x=theta[1], sigma_y=theta[2])
 
+    def run2(cx, stream):
+        return b.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn,
+                                  resample_algorithm="SISR", resample_fn=args.resample_fn, return_particles=False,
+                                  seed=1405, stream=stream, ctx=cx, phi=theta[0], sigma_x=theta[1], sigma_y=theta[2])
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -216,6 +221,19 @@ def main():
                 "workload": "%d independent bootstrap filters, N=%d, T=%d, SISAR + stratified, one kernel launch" % (Fb, Nb, T),
                 "particle_steps_per_s": Fb * Nb * T / dt2, "filters_per_s": Fb / dt2, "device_ms": ob["device_ms"],
                 "one_at_a_time_filters_per_s": 1.0 / dt3, "speedup_vs_one_at_a_time": dt3 / (dt2 / Fb)}
+        if not args.no_batch and N <= 1 << 20:
+            # independent filter runs in flight on ONE GPU (what pmmh(chains_per_gpu=2) does with two chains): each run
+            # leaves most of the chip idle between its dependent launches.  Informational; `value` stays one run at a time.
+            from concurrent.futures import ThreadPoolExecutor
+            ctx2 = [ctx, b.Context(dev_index if world > 1 else 0, N, 1)]
+            with ThreadPoolExecutor(2) as ex:
+                list(ex.map(lambda i: run2(ctx2[i], 5000 + i), range(2)))
+                t4 = time.perf_counter()
+                list(ex.map(lambda i: [run2(ctx2[i], 6000 + 10 * i + r) for r in range(2)], range(2)))
+                dt4 = time.perf_counter() - t4
+            out["two_runs_in_flight"] = {"particle_steps_per_s": 4 * float(N) * T / dt4,
+                                         "note": "2 host threads x 2 contexts (HIP streams), 2 runs each, same workload"}
+            ctx2[1].close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ys, theta, rank)
     if dist is not None:
