@@ -687,7 +687,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (rmpf && !(cfg->move_sd > 0)) ARGFAIL("bssm_pf_run_batch: RMPF needs move_sd > 0");
     if (rmpf && (cfg->z_move || cfg->u_move)) ARGFAIL("bssm_pf_run_batch: injected draws are not available in the batched path");
     if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run_batch: unknown resample_algorithm");
-    if (cfg->resample_fn != BSSM_STRATIFIED && cfg->resample_fn != BSSM_SYSTEMATIC) ARGFAIL("bssm_pf_run_batch: stratified or systematic resampling only");
+    if (cfg->resample_fn < 0 || cfg->resample_fn > 2) ARGFAIL("bssm_pf_run_batch: unknown resample_fn");
     if (cfg->z_init || cfg->z_trans || cfg->u_res || cfg->return_particles || cfg->return_ancestors)
         ARGFAIL("bssm_pf_run_batch: injected draws and histories are not available in the batched path");
     if (cfg->n_theta < (sir ? 5 : 3)) ARGFAIL("bssm_pf_run_batch: theta rows must hold (phi, sigma_x, sigma_y) or (lambda, gamma, n_total, s0, i0)");
@@ -748,7 +748,9 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     if (g_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 40 * 8, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 40 * 8, c->stream)); g.phase_cycles = (long long*)d_ph; }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     const int alg = apf ? 1 : rmpf ? 2 : 0;
-#define BATCH(M, A) LAUNCH(c, "k_pf_batch", (k_pf_batch<M, A>), F, NT, 0, g)
+    const size_t bshm = (cfg->resample_fn == BSSM_MULTINOMIAL) ? (size_t)EB * sizeof(double) : 0;     // the exact cum_sum for the inverse-CDF search
+#define BATCH(M, A) do { if (bshm) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pf_batch<M, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bshm)); \
+                         LAUNCH(c, "k_pf_batch", (k_pf_batch<M, A>), F, NT, bshm, g); } while (0)
     if (cfg->model == BSSM_MODEL_LG) { if (alg == 0) BATCH(0, 0); else if (alg == 1) BATCH(0, 1); else BATCH(0, 2); }
     else if (cfg->model == BSSM_MODEL_AR1SIN) { if (alg == 0) BATCH(1, 0); else if (alg == 1) BATCH(1, 1); else BATCH(1, 2); }
     else { if (alg == 0) BATCH(2, 0); else BATCH(2, 1); }

@@ -1692,10 +1692,10 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
 }
 
 // multinomial: inverse CDF on the exact cum_sum (distributional parity only)
-__global__ __launch_bounds__(NT) void k_multinomial(const double* __restrict__ cum, long long nw, int n, ApplyArgs a, DevState* st)
+__device__ __forceinline__ void multinomial_block(double* sh4, const int bidx, const double* __restrict__ cum, long long nw, int n,
+                                                  const ApplyArgs& a, DevState* st)
 {
     if (st->dead || !st->do_resample || st->flags) return;
-    __shared__ double sh4[4];
     const int call = st->cur_call;
     UniformSrc us;
     us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
@@ -1705,7 +1705,7 @@ __global__ __launch_bounds__(NT) void k_multinomial(const double* __restrict__ c
     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
     for (int r = 0; r < EL; r++) {
-        const long long i = (long long)blockIdx.x * EB + threadIdx.x + NT * r;
+        const long long i = (long long)bidx * EB + threadIdx.x + NT * r;
         if (i < n) {
             const double u = us((int32_t)i);
             long long lo = 0, hi = nw - 1;
@@ -1725,8 +1725,14 @@ __global__ __launch_bounds__(NT) void k_multinomial(const double* __restrict__ c
     if (a.se_part) {
         acc0 = block_sum(acc0, sh4);
         if (a.dim > 1) acc1 = block_sum(acc1, sh4);
-        if (threadIdx.x == 0) { a.se_part[(long long)blockIdx.x * a.dim] = acc0; if (a.dim > 1) a.se_part[(long long)blockIdx.x * a.dim + 1] = acc1; }
+        if (threadIdx.x == 0) { a.se_part[(long long)bidx * a.dim] = acc0; if (a.dim > 1) a.se_part[(long long)bidx * a.dim + 1] = acc1; }
     }
+}
+
+__global__ __launch_bounds__(NT) void k_multinomial(const double* __restrict__ cum, long long nw, int n, ApplyArgs a, DevState* st)
+{
+    __shared__ double sh4[4];
+    multinomial_block(sh4, (int)blockIdx.x, cum, nw, n, a, st);
 }
 
 // resample_move_filter's move step (R/particle_filter_core.R:226-234) for the built-in random-walk Metropolis move
@@ -2002,6 +2008,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
     __shared__ double pm1, ps1, pq1, ainw1, ainp1;
     __shared__ double sep[2];
     __shared__ uint64_t cin1;
+    extern __shared__ __attribute__((aligned(16))) double CUM[];       // [EB], multinomial resampling only (sized by the launch)
     const int fi = blockIdx.x, t = threadIdx.x;
     const long long N = g.N;
     const int T = g.T;
@@ -2075,8 +2082,13 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             aa.xsrc = xa; aa.xdst = xb; aa.dim = D; aa.xstride = N; aa.auxsrc = AUXLW; aa.auxdst = AUXG; aa.se_part = nullptr; aa.nstage = 0;
             if (g.resample_fn == 1) {
                 if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, aa, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, aa, &st);
-            } else {
+            } else if (g.resample_fn == 0) {
                 if (lit) apply_block<0, true>(sm, tin, Tl, Tbegin, 0, 1, aa, &st); else apply_block<0, false>(sm, tin, Tl, Tbegin, 0, 1, aa, &st);
+            } else {                                                                      // multinomial: exact cum_sum, then inverse-CDF search
+                aa.cum_out = CUM;
+                if (lit) apply_block<2, true>(sm, tin, Tl, Tbegin, 0, 1, aa, &st); else apply_block<2, false>(sm, tin, Tl, Tbegin, 0, 1, aa, &st);
+                __syncthreads();
+                multinomial_block(sm.sh4, 0, CUM, N, (int)N, aa, &st);
             }
             __syncthreads();
             { double* tmp = xa; xa = xb; xb = tmp; }
@@ -2115,8 +2127,13 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         a.xsrc = xa; a.xdst = xb; a.dim = D; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = sep; a.nstage = 0;
         if (g.resample_fn == 1) {                                                         // systematic
             if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
-        } else {                                                                          // stratified
+        } else if (g.resample_fn == 0) {                                                  // stratified
             if (lit) apply_block<0, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<0, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
+        } else {                                                                          // multinomial: exact cum_sum, then inverse-CDF search
+            a.cum_out = CUM;
+            if (lit) apply_block<2, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<2, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
+            __syncthreads();
+            multinomial_block(sm.sh4, 0, CUM, N, (int)N, a, &st);
         }
         __syncthreads();
         PH(2)

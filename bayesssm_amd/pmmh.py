@@ -230,7 +230,7 @@ def batch_eligible(pf_wrapper, model, num_particles, resample_fn):
     """Can this filter configuration run in the one-workgroup-per-filter kernel (bssm_pf_run_batch)?"""
     from .filters import batch_max_particles
     return (model in ("lg", "ar1sin", "sir")
-            and resample_fn in ("stratified", "systematic") and int(num_particles) <= batch_max_particles())
+            and resample_fn in ("stratified", "systematic", "multinomial") and int(num_particles) <= batch_max_particles())
 
 
 def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, proposal_covs, transform, priors,

@@ -167,8 +167,7 @@ int bssm_pf_run(bssm_ctx* ctx, const bssm_pf_config* cfg, bssm_pf_result* res);
  * pilot (R/pmmh_tuning.R:111-151): launch-bound one at a time.  bssm_pf_run_batch runs n_filters independent bootstrap
  * filters -- same data and settings (cfg), one theta / seed / stream each -- in ONE kernel launch, one workgroup per
  * filter with the whole T loop on chip.  Each filter's outputs are bit-identical to bssm_pf_run with that theta, seed
- * and stream.  Limits: num_particles <= bssm_pf_batch_max_particles() (2048), stratified or systematic resampling,
- * device generator only (cfg->theta, seed, stream, z_*, u_res, return_* are not used). */
+ * and stream.  Limits: num_particles <= bssm_pf_batch_max_particles() (2048), device generator only (cfg->theta, seed, stream, z_*, u_res, return_* are not used). */
 typedef struct {
     double* loglike;          /* [n_filters]                                                    */
     double* state_est;        /* [n_filters][T+1][d] or NULL  (d = 2 for the SIR model)         */
@@ -231,7 +230,7 @@ int bssm_pmmh_chain(bssm_ctx* ctx, const bssm_pmmh_config* cfg, bssm_pmmh_result
 
 /* n_chains chains advancing in lock-step over bssm_pf_run_batch: iteration i of every chain is ONE kernel launch (one
  * workgroup per chain).  The chains must share data, filter settings and m, and meet bssm_pf_run_batch's limits
- * (N <= 2048, stratified / systematic).  ress[k] is exactly what bssm_pmmh_chain returns for
+ * (N <= 2048).  ress[k] is exactly what bssm_pmmh_chain returns for
  * cfgs[k]; device_ms reports the total device time divided by n_chains. */
 int bssm_pmmh_chains_batch(bssm_ctx* ctx, int n_chains, const bssm_pmmh_config* cfgs, bssm_pmmh_result* ress);
 

@@ -301,3 +301,27 @@ def test_batch_rmpf_matches_single_bitwise(model, N, rf):
         assert out["loglike"][k] == ref["loglike"]
         np.testing.assert_array_equal(out["ess"][k], ref["ess"])
         np.testing.assert_array_equal(out["state_est"][k], ref["state_est"])
+
+
+@pytest.mark.parametrize("alg", ["BPF", "APF"])
+@pytest.mark.parametrize("N,ra", [(90, "SISAR"), (1200, "SISR")])
+def test_batch_multinomial_matches_single_bitwise(alg, N, ra):
+    """Multinomial resampling (inverse-CDF search on the exact cum_sum, src/resampling.cpp:5-13 in law) in the batched kernel."""
+    import bayesssm_amd as b
+    m = b.models.linear_gaussian()
+    y = _data(12)
+    thetas = np.array([[0.8, 1.0, 0.7], [0.5, 1.2, 0.9]])
+    if alg == "BPF":
+        out = b.bootstrap_filter_batch(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 17, [4, 5],
+                                       resample_algorithm=ra, resample_fn="multinomial")
+    else:
+        out = b.auxiliary_filter_batch(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, m.aux_log_likelihood_fn, thetas,
+                                       17, [4, 5], resample_algorithm=ra, resample_fn="multinomial")
+    for k in range(2):
+        kw = dict(return_particles=False, seed=17, stream=4 + k, resample_algorithm=ra, resample_fn="multinomial",
+                  phi=thetas[k][0], sigma_x=thetas[k][1], sigma_y=thetas[k][2])
+        ref = (b.bootstrap_filter(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, **kw) if alg == "BPF" else
+               b.auxiliary_filter(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, m.aux_log_likelihood_fn, **kw))
+        assert out["loglike"][k] == ref["loglike"]
+        np.testing.assert_array_equal(out["ess"][k], ref["ess"])
+        np.testing.assert_array_equal(out["state_est"][k], ref["state_est"])
