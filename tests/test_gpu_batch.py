@@ -325,3 +325,26 @@ def test_batch_multinomial_matches_single_bitwise(alg, N, ra):
         assert out["loglike"][k] == ref["loglike"]
         np.testing.assert_array_equal(out["ess"][k], ref["ess"])
         np.testing.assert_array_equal(out["state_est"][k], ref["state_est"])
+
+
+def test_batch_empty_series_and_bad_arguments():
+    """T = 0 (no observations): only the t = 0 rows; argument errors come back as exceptions, not crashes."""
+    import bayesssm_amd as b
+    m = b.models.linear_gaussian()
+    thetas = np.array([[0.8, 1.0, 0.7], [0.5, 1.2, 0.9]])
+    out = b.bootstrap_filter_batch(np.zeros(0), 50, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 3)
+    ref = b.bootstrap_filter(np.zeros(0), 50, m.init_fn, m.transition_fn, m.log_likelihood_fn, return_particles=False, seed=3,
+                             stream=1, phi=0.5, sigma_x=1.2, sigma_y=0.9)
+    assert out["loglike"].tolist() == [0.0, 0.0] and out["state_est"].shape == (2, 1) and out["ess"][1, 0] == 50.0
+    assert out["state_est"][1, 0] == ref["state_est"][0]
+    with pytest.raises(ValueError):
+        b.bootstrap_filter_batch(np.array([0.1, np.nan]), 50, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 3)
+    with pytest.raises(ValueError):
+        b.bootstrap_filter_batch(np.zeros(3), 50, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas[:, :2], 3)
+    with pytest.raises(Exception):
+        b.bootstrap_filter_batch(np.zeros(3), 0, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 3)
+    # a non-positive sigma_y makes every log-weight NaN: the filter reports it per filter instead of returning garbage
+    bad = b.bootstrap_filter_batch(np.zeros(3), 50, m.init_fn, m.transition_fn, m.log_likelihood_fn,
+                                   np.array([[0.8, 1.0, 0.7], [0.8, 1.0, -1.0]]), 3)
+    assert bad["status"][0] == 0 and np.isfinite(bad["loglike"][0])
+    assert bad["status"][1] != 0 or not np.isfinite(bad["loglike"][1])
