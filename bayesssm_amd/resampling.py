@@ -6,14 +6,19 @@ import numpy as np
 
 from . import _lib
 
-_rng = np.random.default_rng()
+from .rrng import RRandom
+
+# R's global generator (Mersenne-Twister, R's own seeding): after set_seed(s) the shims draw the uniforms that
+# R::runif / Rcpp::runif draw after set.seed(s) (src/resampling.cpp:28,55), so systematic and stratified ancestors are
+# the ones the reference returns for that seed.  (Multinomial: the reference goes through Rcpp::sample, a different
+# algorithm -- same law, not the same stream.)
+_rng = RRandom(int(np.random.default_rng().integers(1, 2 ** 31 - 1)))
 
 
 def set_seed(seed):
-    """Seeds the host generator that stands in for R's global RNG (set.seed)
-    for the uniform draws of the resamplers."""
+    """set.seed(seed) for the host generator behind the resampling shims (R-compatible, see rrng.py)."""
     global _rng
-    _rng = np.random.default_rng(seed)
+    _rng = RRandom(seed)
 
 
 def _ptr(a):
@@ -50,14 +55,14 @@ def _resample(kind, n, weights, U, ctx, return_cum=False, return_stats=False):
 def resample_systematic_cpp(n, weights, U=None, ctx=None, **kw):
     """resample_systematic_cpp(n, weights) (src/resampling.cpp:43-66).  U: the R::runif(0,1) draw."""
     if U is None:
-        U = _rng.random()
+        U = _rng.unif_rand()
     return _resample("systematic", n, weights, [U], ctx, **kw)
 
 
 def resample_stratified_cpp(n, weights, U=None, ctx=None, **kw):
     """resample_stratified_cpp(n, weights) (src/resampling.cpp:16-40).  U: the Rcpp::runif(n) draws."""
     if U is None:
-        U = _rng.random(int(n))
+        U = _rng.runif(int(n))
     return _resample("stratified", n, weights, U, ctx, **kw)
 
 
@@ -65,7 +70,7 @@ def resample_multinomial_cpp(n, weights, U=None, ctx=None, **kw):
     """resample_multinomial_cpp(n, weights) (src/resampling.cpp:5-13); inverse-CDF draws
     (distributional parity with Rcpp::sample only)."""
     if U is None:
-        U = _rng.random(int(n))
+        U = _rng.runif(int(n))
     return _resample("multinomial", n, weights, U, ctx, **kw)
 
 

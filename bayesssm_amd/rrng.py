@@ -1,0 +1,120 @@
+"""R's default random number generator on the host: Mersenne-Twister with R's seeding (`set.seed`) and the
+inversion `rnorm` -- so that the resampling shims draw, after `set_seed(s)`, the uniforms R's `R::runif` /
+`Rcpp::runif` would draw after `set.seed(s)` (the reference draws inside its C++: src/resampling.cpp:28,55 under
+Rcpp::RNGScope, src/RcppExports.cpp:18,30,42).
+
+Restated from R's documented algorithm (R sources src/main/RNG.c: Randomize / RNG_Init / MT_sgenrand / MT_genrand /
+fixup, and src/nmath/snorm.c INVERSION; third-party, absent from /root/reference).  Pinned by R's widely published
+known answers -- see tests/test_abi_and_host.py::test_r_compatible_rng:
+    set.seed(1);   runif(3)  ->  0.2655087 0.3721239 0.5728534
+    set.seed(42);  runif(3)  ->  0.9148060 0.9370754 0.2861395
+    set.seed(123); rnorm(3)  -> -0.56047565 -0.23017749 1.55870831
+"""
+import math
+
+import numpy as np
+
+_N, _M = 624, 397
+_UPPER, _LOWER = 0x80000000, 0x7FFFFFFF
+_I2_32M1 = 2.328306437080797e-10          # 1 / (2^32 - 1)
+_BIG = 134217728                          # 2^27 (snorm.c INVERSION)
+
+
+class RRandom:
+    """R's "Mersenne-Twister" + "Inversion" generator state after set.seed(seed)."""
+
+    def __init__(self, seed):
+        self.set_seed(seed)
+
+    def set_seed(self, seed):
+        s = int(seed) & 0xFFFFFFFF
+        for _ in range(50):                                  # initial scrambling (RNG_Init)
+            s = (69069 * s + 1) & 0xFFFFFFFF
+        st = np.empty(_N + 1, dtype=np.uint32)
+        for j in range(_N + 1):                              # i_seed[0..624] = successive LCG values
+            s = (69069 * s + 1) & 0xFFFFFFFF
+            st[j] = s
+        self.mt = st[1:].astype(np.uint64)                   # dummy[1..624] = mt
+        self.mti = _N                                        # FixupSeeds: dummy[0] = 624
+        self.buf = None
+
+    def _refill(self):
+        """The next 624 state words (vectorised: each chunk only reads words the sequential loop has not yet rewritten
+        or has already rewritten), then their tempered outputs as doubles in [0, 1)."""
+        mt = self.mt.astype(np.uint32)
+        def step(lo, hi, src):
+            y = (mt[lo:hi] & np.uint32(_UPPER)) | (mt[lo + 1:hi + 1] & np.uint32(_LOWER))
+            mt[lo:hi] = src ^ (y >> np.uint32(1)) ^ np.where((y & np.uint32(1)) != 0, np.uint32(0x9908B0DF), np.uint32(0))
+        step(0, _N - _M, mt[_M:_N].copy())                                   # kk = 0..226 reads mt[kk + 397] (old)
+        step(_N - _M, 2 * (_N - _M), mt[0:_N - _M].copy())                   # kk = 227..453 reads mt[kk - 227] (new)
+        step(2 * (_N - _M), _N - 1, mt[_N - _M:_N - 1 - (_N - _M)].copy())   # kk = 454..622
+        y = (mt[_N - 1] & np.uint32(_UPPER)) | (mt[0] & np.uint32(_LOWER))
+        mt[_N - 1] = mt[_M - 1] ^ (y >> np.uint32(1)) ^ (np.uint32(0x9908B0DF) if (int(y) & 1) else np.uint32(0))
+        self.mt = mt.astype(np.uint64)
+        y = mt.copy()
+        y ^= y >> np.uint32(11)
+        y ^= (y << np.uint32(7)) & np.uint32(0x9D2C5680)
+        y ^= (y << np.uint32(15)) & np.uint32(0xEFC60000)
+        y ^= y >> np.uint32(18)
+        x = y.astype(np.float64) * 2.3283064365386963e-10
+        x = np.where(x <= 0.0, 0.5 * _I2_32M1, x)                            # fixup(): strictly inside (0, 1)
+        self.buf = np.where(1.0 - x <= 0.0, 1.0 - 0.5 * _I2_32M1, x)
+        self.mti = 0
+
+    def unif_rand(self):
+        if self.mti >= _N:
+            self._refill()
+        x = float(self.buf[self.mti]); self.mti += 1
+        return x
+
+    def runif(self, n):
+        n = int(n)
+        out = np.empty(n, dtype=np.float64)
+        k = 0
+        while k < n:
+            if self.mti >= _N:
+                self._refill()
+            take = min(n - k, _N - self.mti)
+            out[k:k + take] = self.buf[self.mti:self.mti + take]
+            self.mti += take; k += take
+        return out
+
+    def norm_rand(self):
+        u = self.unif_rand()
+        u = int(_BIG * u) + self.unif_rand()
+        return qnorm(u / _BIG)
+
+    def rnorm(self, n, mean=0.0, sd=1.0):
+        return np.array([mean + sd * self.norm_rand() for _ in range(int(n))], dtype=np.float64)
+
+
+def qnorm(p):
+    """Standard normal quantile, Wichura's AS 241 PPND16 (the algorithm of R's qnorm5)."""
+    q = p - 0.5
+    if abs(q) <= 0.425:
+        r = 0.180625 - q * q
+        return q * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r
+                         + 45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r
+                      + 133.14166789178437745) * r + 3.387132872796366608) / \
+            (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r
+                 + 21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r
+              + 42.313330701600911252) * r + 1.0)
+    r = p if q < 0 else 1.0 - p
+    r = math.sqrt(-math.log(r))
+    if r <= 5.0:
+        r -= 1.6
+        val = (((((((r * 7.7454501427834140764e-4 + 0.0227238449892691845833) * r + 0.24178072517745061177) * r
+                   + 1.27045825245236838258) * r + 3.64784832476320460504) * r + 5.7694972214606914055) * r
+                + 4.6303378461565452959) * r + 1.42343711074968357734) / \
+            (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r + 0.0151986665636164571966) * r
+                 + 0.14810397642748007459) * r + 0.68976733498510000455) * r + 1.6763848301838038494) * r
+              + 2.05319162663775882187) * r + 1.0)
+    else:
+        r -= 5.0
+        val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r + 0.0012426609473880784386) * r
+                   + 0.026532189526576123093) * r + 0.29656057182850489123) * r + 1.7848265399172913358) * r
+                + 5.4637849111641143699) * r + 6.6579046435011037772) / \
+            (((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r + 1.8463183175100546818e-5) * r
+                 + 7.868691311456132591e-4) * r + 0.0148753612908506148525) * r + 0.13692988092273580531) * r
+              + 0.59983224619672312656) * r + 1.0)
+    return -val if q < 0 else val

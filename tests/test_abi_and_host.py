@@ -139,3 +139,24 @@ def test_pilot_chain_logic():
     with pytest.raises(ValueError, match="Initial parameter values are invalid"):
         run_pilot_chain(pf, 10, 100, 5, [prior_normal(0, 1), prior_exponential(1)], 0.5, ["identity", "log"],
                         [0.2, -1.0], np.random.default_rng(1), message=lambda *_: None)
+
+
+def test_r_compatible_rng():
+    """The host generator behind set_seed() is R's Mersenne-Twister with R's seeding and inversion rnorm (bayesssm_amd/rrng.py).
+    Pinned by R's own, widely published known answers (set.seed(s); runif(3) / rnorm(3)); with them the resampling shims
+    consume, after set_seed(s), the uniforms the reference's C++ draws after set.seed(s) (src/resampling.cpp:28,55)."""
+    from bayesssm_amd.rrng import RRandom
+    kat_unif = {1: (0.2655087, 0.3721239, 0.5728534), 42: (0.9148060, 0.9370754, 0.2861395), 123: (0.2875775, 0.7883051, 0.4089769)}
+    kat_norm = {1: (-0.6264538, 0.1836433, -0.8356286), 42: (1.37095845, -0.56469817, 0.36312841),
+                123: (-0.56047565, -0.23017749, 1.55870831)}
+    for seed, want in kat_unif.items():
+        np.testing.assert_allclose(RRandom(seed).runif(3), want, rtol=0, atol=5e-8)
+    for seed, want in kat_norm.items():
+        np.testing.assert_allclose(RRandom(seed).rnorm(3), want, rtol=0, atol=5e-8)
+    # block boundaries of the vectorised generator: one draw at a time == in bulk, across several 624-word refills
+    a, g = RRandom(1405).runif(2000), RRandom(1405)
+    assert (a == np.array([g.unif_rand() for _ in range(2000)])).all() and a.min() > 0 and a.max() < 1
+    # what set.seed(1); resample_systematic_cpp(5, c(.1,.5,.1,.15,.15)) returns in R: U = 0.2655087,
+    # u_i = (i + U)/5 = .053 .253 .453 .653 .853 against cum = .1 .6 .7 .85 1   (src/resampling.cpp:55-63)
+    from oracle import oracle as orc
+    assert orc.resample_systematic(5, [0.1, 0.5, 0.1, 0.15, 0.15], RRandom(1).unif_rand()).tolist() == [1, 2, 2, 3, 5]

@@ -187,3 +187,22 @@ def test_runs_of_equal_weights_stay_on_the_fast_path(B, ctx, oracle, n, distinct
     assert cum.tobytes() == wcum.tobytes()
     assert (got == want).all()
     assert int(stats[1]) == 0 and int(stats[2]) <= 64 * 8, stats      # no serial walks; at most a few HARD leaves re-run (8 terms each)
+
+
+def test_set_seed_draws_r_uniforms(B, ctx, oracle):
+    """After set_seed(s) the shims draw R's uniforms for set.seed(s): the device result equals the oracle fed with the
+    R-compatible generator's draws, for the systematic (one draw) and the stratified (n draws, in index order) resampler."""
+    from bayesssm_amd.rrng import RRandom
+    w = [0.1, 0.5, 0.1, 0.15, 0.15]
+    B.set_seed(1)
+    assert B.resample_systematic_cpp(5, w, ctx=ctx).tolist() == [1, 2, 2, 3, 5]
+    rng = np.random.default_rng(3)
+    w2 = rng.random(5000)
+    B.set_seed(42)
+    got = B.resample_stratified_cpp(5000, w2, ctx=ctx)
+    assert (got == oracle.resample_stratified(5000, w2, RRandom(42).runif(5000))).all()
+    g = RRandom(7)
+    g.runif(3)                                   # the generator advances across calls, like R's global stream
+    B.set_seed(7)
+    B.resample_stratified_cpp(3, [1.0, 1.0, 1.0], ctx=ctx)
+    assert (B.resample_systematic_cpp(5000, w2, ctx=ctx) == oracle.resample_systematic(5000, w2, g.unif_rand())).all()
