@@ -118,3 +118,18 @@ def qnorm(p):
                  + 7.868691311456132591e-4) * r + 0.0148753612908506148525) * r + 0.13692988092273580531) * r
               + 0.59983224619672312656) * r + 1.0)
     return -val if q < 0 else val
+
+
+def readme_series(seed=1405, t_val=20, phi=0.8, sigma_x=1.0, sigma_y=0.5):
+    """The data set of the reference's README (README.md:97-114) -- `set.seed(1405)` followed by its `rnorm(1, ...)` calls,
+    in order -- regenerated with the R-compatible generator: (x[0..t_val], y[1..t_val])."""
+    g = RRandom(seed)
+    rnorm1 = lambda mean, sd: mean + sd * g.norm_rand()      # noqa: E731   rnorm(1, mean, sd) = mean + sd * norm_rand()
+    init_state = rnorm1(0.0, 1.0)
+    x, y = np.empty(t_val), np.empty(t_val)
+    x[0] = phi * init_state + math.sin(init_state) + rnorm1(0.0, sigma_x)
+    y[0] = x[0] + rnorm1(0.0, sigma_y)
+    for t in range(1, t_val):
+        x[t] = phi * x[t - 1] + math.sin(x[t - 1]) + rnorm1(0.0, sigma_x)
+        y[t] = x[t] + rnorm1(0.0, sigma_y)
+    return np.concatenate([[init_state], x]), y

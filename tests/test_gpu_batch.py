@@ -348,3 +348,30 @@ def test_batch_empty_series_and_bad_arguments():
                                    np.array([[0.8, 1.0, 0.7], [0.8, 1.0, -1.0]]), 3)
     assert bad["status"][0] == 0 and np.isfinite(bad["loglike"][0])
     assert bad["status"][1] != 0 or not np.isfinite(bad["loglike"][1])
+
+
+def test_readme_example_posterior_matches_published_table():
+    """End to end against the reference's one published answer: the README's PMMH example (README.md:150-208) on the README's
+    own data (set.seed(1405) series, regenerated with the R-compatible generator).  The README prints, from 2 x 450 poorly
+    mixed draws (ESS 8 / 15 / 36):  phi 0.76 (sd 0.12, 2.5 % 0.55, 97.5 % 0.97), sigma_x 0.78 (0.56), sigma_y 0.89 (0.36).
+    Long chains here (Rhat ~ 1.00) must land inside that table's Monte-Carlo error."""
+    import warnings
+    import bayesssm_amd as b
+    from bayesssm_amd.rrng import readme_series
+    _, ys = readme_series()
+    m = b.models.ar1_sin()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = b.pmmh(pf_wrapper=b.bootstrap_filter, y=ys, m=8000, init_fn=m.init_fn, transition_fn=m.transition_fn,
+                   log_likelihood_fn=m.log_likelihood_fn,
+                   log_priors={"phi": b.prior_uniform(0, 1), "sigma_x": b.prior_exponential(1), "sigma_y": b.prior_exponential(1)},
+                   pilot_init_params=[{"phi": 0.4, "sigma_x": 0.4, "sigma_y": 0.4}, {"phi": 0.8, "sigma_x": 0.8, "sigma_y": 0.8},
+                                      {"phi": 0.6, "sigma_x": 1.0, "sigma_y": 0.5}, {"phi": 0.5, "sigma_x": 0.7, "sigma_y": 0.9}],
+                   burn_in=1500, num_chains=4, seed=1405, num_particles=300, proposal_cov=np.diag([0.02, 0.08, 0.04]))
+    th = r["theta_chain"]
+    assert max(r["diagnostics"]["rhat"].values()) < 1.05
+    assert abs(th["phi"].mean() - 0.76) < 0.09 and abs(th["phi"].std() - 0.12) < 0.04
+    q = np.quantile(th["phi"], [0.025, 0.975])
+    assert abs(q[0] - 0.55) < 0.07 and abs(q[1] - 0.97) < 0.04
+    assert abs(th["sigma_x"].mean() - 0.78) < 0.45 and abs(th["sigma_y"].mean() - 0.89) < 0.30     # README: ESS 15 and 36
+    assert abs(np.quantile(th["sigma_x"], 0.975) - 1.85) < 0.3 and abs(np.quantile(th["sigma_y"], 0.975) - 1.45) < 0.3

@@ -195,10 +195,13 @@ def test_kalman_and_structure_full_n(B, ctx, oracle):
 
 
 def test_readme_c1(B, ctx, oracle):
-    """BASELINE C1: README AR(1)+sin, T=20, N=100, bootstrap_filter defaults (SISAR, stratified)."""
+    """BASELINE C1: README AR(1)+sin, T=20, N=100, bootstrap_filter defaults (SISAR, stratified), on the README's own
+    series: set.seed(1405) + its rnorm calls (README.md:97-114) through the R-compatible generator."""
+    from bayesssm_amd.rrng import readme_series
     rng = np.random.default_rng(1405)
     T, N = 20, 100
-    ys = _simulate(rng, T, 0.8, 1.0, 0.5, sin=True)
+    _, ys = readme_series()
+    assert ys.shape == (T,) and abs(ys[0] - 0.4135) < 5e-4
     d = _draws(rng, oracle, "BPF", T, N, "stratified")
     m = B.models.ar1_sin()
     res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, draws=d, ctx=ctx,
@@ -231,8 +234,8 @@ def test_pmmh_with_pilot(B, ctx, oracle):
     """pmmh() end to end with the pilot (R/pmmh.R:353-376 + R/pmmh_tuning.R): README-sized run
     (README.md:150-195: m = 500, burn_in = 50, 2 chains, pilot_m = 200)."""
     import warnings
-    rng = np.random.default_rng(1405)
-    ys = _simulate(rng, 20, 0.8, 1.0, 0.5, sin=True)
+    from bayesssm_amd.rrng import readme_series
+    _, ys = readme_series()                      # the README's data (set.seed(1405), README.md:97-114)
     m = B.models.ar1_sin()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -2,13 +2,9 @@
 chains in lock-step over the batched kernel vs one chain at a time over the multi-launch path."""
 import sys, time, warnings; sys.path.insert(0, '.')
 import numpy as np, bayesssm_amd as b
-rng = np.random.default_rng(1405)
+from bayesssm_amd.rrng import readme_series
 T = 20
-x, ys = rng.standard_normal(), []
-for t in range(T):
-    x = 0.8 * x + np.sin(x) + rng.standard_normal()
-    ys.append(x + 0.5 * rng.standard_normal())
-ys = np.array(ys)
+_, ys = readme_series()                  # the README's own series: set.seed(1405) + its rnorm calls (README.md:97-114)
 m = b.models.ar1_sin()
 for chains, N, iters in ((4, 200, 2000), (4, 1000, 1000), (64, 1000, 500)):
     kw = dict(pf_wrapper=b.bootstrap_filter, y=ys, m=iters, init_fn=m.init_fn, transition_fn=m.transition_fn,
