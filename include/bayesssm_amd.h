@@ -17,8 +17,12 @@
  *                          via bootstrap_filter / auxiliary_filter
  *                                                              R/bootstrap_filter.R:129-171
  *                                                              R/auxiliary_filter.R:163-216
+ *                          (also resample_move_filter, R/resample_move_filter.R:190-236, with the built-in move)
+ *   bssm_pf_run_batch      the same filters, many at once: the pilot's repeated runs (R/pmmh_tuning.R:29-64) and
+ *                          PMMH's small filters (N <= 1000, R/pmmh_tuning.R:55-57); one workgroup per filter
  *   bssm_pmmh_chain        the per-chain loop of pmmh()        R/pmmh.R:403-415,422-500
  *                          (+ R/utils.R:102-152 transforms)
+ *   bssm_pmmh_chains_batch the chain fan-out of pmmh()         R/pmmh.R:511-531, chains in lock-step over the batch
  *
  * Random draws.  The reference takes them from R's global RNG
  * (Rcpp::RNGScope, src/RcppExports.cpp:18,30,42).  Here they are either
@@ -166,8 +170,9 @@ int bssm_pf_run(bssm_ctx* ctx, const bssm_pf_config* cfg, bssm_pf_result* res);
  * The reference runs its filters at N <= 1000 inside PMMH (R/pmmh.R:403-415,445-457) and 100 of them at N = 100 in the
  * pilot (R/pmmh_tuning.R:111-151): launch-bound one at a time.  bssm_pf_run_batch runs n_filters independent bootstrap
  * filters -- same data and settings (cfg), one theta / seed / stream each -- in ONE kernel launch, one workgroup per
- * filter with the whole T loop on chip.  Each filter's outputs are bit-identical to bssm_pf_run with that theta, seed
- * and stream.  Limits: num_particles <= bssm_pf_batch_max_particles() (2048), device generator only (cfg->theta, seed, stream, z_*, u_res, return_* are not used). */
+ * filter with the whole T loop on chip (cfg->algorithm: BPF, APF or RMPF; every built-in model and resampler).  Each
+ * filter's outputs are bit-identical to bssm_pf_run with that theta, seed and stream.  Limits: num_particles <=
+ * bssm_pf_batch_max_particles() (2048), device generator only (cfg->theta, seed, stream, z_*, u_res, return_* are not used). */
 typedef struct {
     double* loglike;          /* [n_filters]                                                    */
     double* state_est;        /* [n_filters][T+1][d] or NULL  (d = 2 for the SIR model)         */
