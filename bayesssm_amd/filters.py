@@ -193,11 +193,47 @@ def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
     build: seed, stream, draws, ctx, return_ancestors."""
     resample_algorithm = _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")
     resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    r_seed = kwargs.pop("r_seed", None)
     ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
     model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
     theta = models.theta_from_kwargs((init_fn, transition_fn, log_likelihood_fn), kwargs)
+    if r_seed is not None:
+        return _r_seeded_bootstrap(y, num_particles, model, theta, obs_times, resample_algorithm, resample_fn, threshold,
+                                   return_particles, int(r_seed), ctl)
     return particle_filter_core(y, num_particles, model, theta, "BPF", obs_times, resample_algorithm, resample_fn,
                                 threshold, return_particles, **ctl)
+
+
+def _r_seeded_bootstrap(y, N, model, theta, obs_times, ra, rf, threshold, return_particles, r_seed, ctl):
+    """bootstrap_filter(..., r_seed = s): the run R makes after `set.seed(s)` when the closures have the README's form
+    (rrng.r_seeded_draws): the draws come from the R-compatible host generator in R's order and enter through the
+    parity mode.  Whether uniforms are consumed at an observation depends on that observation's resample decision, so
+    the draw sequence is the fixed point of "assume decisions -> draw -> run -> read decisions" (at most T rounds; one
+    round for SIS / SISR).  By construction, not verified against R here (no R in this image): R's streams are pinned by
+    R's published known answers, the filter arithmetic by the oracle."""
+    from .rrng import r_seeded_draws
+    if model not in ("lg", "ar1sin"):
+        raise ValueError("r_seed: the scalar Gaussian-observation models only (closures of the README's form)")
+    if rf == "multinomial":
+        raise ValueError("r_seed: the reference's multinomial resampler goes through Rcpp::sample, whose stream is not restated")
+    if ctl.get("draws") is not None:
+        raise ValueError("r_seed and draws are mutually exclusive")
+    T = int(np.asarray(y).size)
+    dec = np.ones(T, dtype=bool) if ra != "SIS" else np.zeros(T, dtype=bool)
+    ctl = {k: v for k, v in ctl.items() if k not in ("seed", "stream", "draws")}
+    for _ in range(T + 1):
+        d = r_seeded_draws(r_seed, T, int(N), rf, dec, obs_times)
+        res = particle_filter_core(y, N, model, theta, "BPF", obs_times, ra, rf, threshold, return_particles, draws=d, **ctl)
+        got = np.asarray(res["_extras"]["resampled"], dtype=bool)
+        early = res["_extras"]["early_return_step"]
+        upto = (early - 1) if early else T                    # after a degenerate early return nothing more is drawn
+        if np.array_equal(got[:upto], dec[:upto]):
+            res["_extras"]["r_seed_decisions"] = dec[:upto].copy()
+            return res
+        k = int(np.flatnonzero(got[:upto] != dec[:upto])[0])  # everything before the first disagreement was drawn right
+        dec[:k + 1] = got[:k + 1]
+        dec[k + 1:] = got[k + 1:]
+    raise RuntimeError("r_seed: the resample decisions did not reach a fixed point")
 
 
 def auxiliary_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn,

@@ -133,3 +133,41 @@ def readme_series(seed=1405, t_val=20, phi=0.8, sigma_x=1.0, sigma_y=0.5):
         x[t] = phi * x[t - 1] + math.sin(x[t - 1]) + rnorm1(0.0, sigma_x)
         y[t] = x[t] + rnorm1(0.0, sigma_y)
     return np.concatenate([[init_state], x]), y
+
+
+def _qnorm_vec(p):
+    return np.array([qnorm(float(v)) for v in p], dtype=np.float64)
+
+
+def rnorm_vec(g, n):
+    """rnorm(n) of generator `g`: norm_rand() n times (two uniforms each, snorm.c INVERSION), in order."""
+    u = g.runif(2 * int(n))
+    v = np.floor(_BIG * u[0::2]) + u[1::2]
+    return _qnorm_vec(v / _BIG)
+
+
+def r_seeded_draws(seed, T, N, resample_fn, resampled, obs_times=None):
+    """The draws R makes inside `bootstrap_filter()` after `set.seed(seed)` when the model closures are of the README's
+    form (README.md:137-146: init_fn = rnorm(num_particles), transition_fn = ... + rnorm(length(particles), 0, sigma_x),
+    no draws in log_likelihood_fn), in R's order (R/particle_filter_core.R:76,127,220-221 -> src/resampling.cpp:28,55):
+        rnorm(N);  per observation: rnorm(N) per transition call, then -- only if that observation resamples --
+        Rcpp::runif(N) (stratified) or R::runif(1) (systematic).
+    `resampled[i]` says whether observation i+1 resamples (it decides whether uniforms are consumed there).
+    Returns the `draws` dict of the filters' parity mode."""
+    g = RRandom(seed)
+    z_init = rnorm_vec(g, N)
+    z_trans, u_res = [], []
+    prev = 0
+    for i in range(T):
+        ot = int(obs_times[i]) if obs_times is not None else i + 1
+        for _ in range(ot - prev):
+            z_trans.append(rnorm_vec(g, N))
+        prev = ot
+        if resampled[i]:
+            u_res.append(g.runif(N) if resample_fn == "stratified" else np.array([g.unif_rand()]))
+    nu = N if resample_fn == "stratified" else 1
+    zt = np.array(z_trans).reshape(-1, N) if z_trans else np.zeros((1, N))
+    ur = np.array(u_res).reshape(-1, nu) if u_res else np.zeros((1, nu))
+    # the filter indexes u_res by resample CALL, and pads to the maximum number of calls
+    pad = np.zeros((max(T - ur.shape[0], 0), nu))
+    return {"z_init": z_init, "z_trans": zt, "u_res": np.vstack([ur, pad]) if nu > 1 else np.concatenate([ur.reshape(-1), pad.reshape(-1)])}

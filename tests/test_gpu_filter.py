@@ -353,3 +353,29 @@ def test_rmpf_beats_bpf_under_degeneracy(B, ctx):
         r1 = B.resample_move_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, m.rw_move_fn(0.1), seed=s, **kw)
         mse_b.append(np.mean((b1["state_est"][1:] - np.array(xs)) ** 2)); mse_r.append(np.mean((r1["state_est"][1:] - np.array(xs)) ** 2))
     assert np.mean(mse_r) < np.mean(mse_b)
+
+
+@pytest.mark.parametrize("ra,rf", [("SISR", "stratified"), ("SISAR", "stratified"), ("SISAR", "systematic"), ("SIS", "stratified")])
+def test_r_seeded_bootstrap_filter(B, ctx, oracle, ra, rf):
+    """bootstrap_filter(..., r_seed = s): draws from the R-compatible generator in R's order (rnorm(N); per observation
+    rnorm(N), then runif only where the filter resamples).  The decisions the draws were generated for are the decisions
+    the run took (fixed point), and the oracle on the same draws agrees."""
+    from bayesssm_amd.rrng import RRandom, readme_series, r_seeded_draws, rnorm_vec
+    _, ys = readme_series()
+    m = B.models.ar1_sin()
+    N = 100
+    res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm=ra, resample_fn=rf,
+                             r_seed=1405, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=0.5)
+    dec = res["_extras"]["r_seed_decisions"]
+    assert (dec == res["_extras"]["resampled"].astype(bool)).all()
+    if ra == "SISR":
+        assert dec.all()
+    if ra == "SIS":
+        assert not dec.any()
+    d = r_seeded_draws(1405, 20, N, rf, dec)
+    ref = oracle.pf_run("ar1sin", (0.8, 1.0, 0.5), ys, N, d["z_init"], d["z_trans"], d["u_res"], resample_algorithm=ra,
+                        resample_fn=rf, return_particles=True)
+    _compare(res, ref, N)
+    # the stream is consumed in R's order: the initial particles are rnorm(N) right after set.seed
+    assert (d["z_init"] == rnorm_vec(RRandom(1405), N)).all()
+    np.testing.assert_allclose(res["particles_history"][0], d["z_init"], rtol=0, atol=0)
