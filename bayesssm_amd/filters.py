@@ -210,7 +210,7 @@ def _r_seeded_bootstrap(y, N, model, theta, obs_times, ra, rf, threshold, return
     parity mode.  Whether uniforms are consumed at an observation depends on that observation's resample decision, so
     the draw sequence is the fixed point of "assume decisions -> draw -> run -> read decisions" (at most T rounds; one
     round for SIS / SISR).  By construction, not verified against R here (no R in this image): R's streams are pinned by
-    R's published known answers, the filter arithmetic by the oracle."""
+    R's published known answers, the filter arithmetic by the parity tests."""
     from .rrng import r_seeded_draws
     if model not in ("lg", "ar1sin"):
         raise ValueError("r_seed: the scalar Gaussian-observation models only (closures of the README's form)")
