@@ -70,7 +70,11 @@ struct DevState {
 };
 
 // dev tool: debug_stop 99 stamps a typical block (block 100 of a large grid), 98 the head block (block 0)
+#ifdef BSSM_DEV_STAMPS
 #define BSSM_STAMP(st, dbg, row, col, cond) do { if (((dbg) == 99 || (dbg) == 98) && (cond)) (st)->stamps[row][col] = clock64(); } while (0)
+#else
+#define BSSM_STAMP(st, dbg, row, col, cond) do { } while (0)      // (the stamps sit in the kernels' hot instruction stream: a dev build only, make DEV=1)
+#endif
 
 // ---------------------------------------------------------------------------
 // small block-level helpers (wave64 shuffles, then LDS across the 4 waves)
@@ -958,7 +962,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
     const double a_in_pre = FROM_LW ? 0.0 : ain[bidx];
     if (s_dead || s_flags) return;
     if (!FROM_LW && !s_do) return;
-    const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0));
+    const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0)); (void)stamper;
     BSSM_STAMP(st, dbg, 2, FROM_LW ? 4 : 0, stamper);
     double v[EL];
     double a_in;
@@ -1281,7 +1285,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     __shared__ uint64_t sseq[65];
     const int t = threadIdx.x;
     // run-state words are fetched together with the block records (checked after the staging barrier)
-    const int s_dead = st->dead, s_do = st->do_resample, dbg0 = st->debug_stop;
+    const int s_dead = st->dead, s_do = st->do_resample, dbg0 = st->debug_stop; (void)dbg0;
     const uint32_t s_flags = st->flags;
     const uint64_t s_total = st->total_bits;
     BSSM_STAMP(st, dbg0, MODE, 0, t == 0);
@@ -1333,7 +1337,9 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     // ---- boundary walk.  One wave; lane j owns the j-th boundary block with its record in registers; the
     // exact state is handed from lane to lane by readlane, so each step costs one record evaluation. ----
     const int nent = nb * CB;
+#ifdef BSSM_DEV_STAMPS
     if (dbg0 == 99 && t == 0) { st->stamps[MODE][8] = nb; st->stamps[MODE][9] = B; }
+#endif
     if (t < 64) {
         const int lane = t;
         const bool fits = (nb <= MAXBND) && (nent <= 64);
@@ -1373,7 +1379,9 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
             const int nstep = (MODE == MODE_P && blast == B - 1) ? nent - 1 : nent;
             const int j0 = walk_chain(wfr, sseq, nstep, s);
             if (lane < j0) { my_in = pure_step(ex, sseq[lane]); my_out = sseq[lane + 1]; }
+#ifdef BSSM_DEV_STAMPS
             if (dbg0 == 99 && t == 0) { st->stamps[MODE][12] = j0; st->stamps[MODE][13] = clock64(); }
+#endif
             for (int j = j0; j < nstep; j++) {
                 bool ok;
                 uint64_t o = stepfn_apply(fn, s, ok);
@@ -1549,7 +1557,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
     us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
     us.key = a.key; us.call = (uint32_t)call;
     const double Usys = (KIND == 1) ? us(0) : 0.0;
-    const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0));
+    const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0)); (void)stamper;
     BSSM_STAMP(st, dbg, 3, 0, stamper);
 #pragma unroll
     for (int k = 0; k < EL; k++) v[k] = v[k] / total;                  // prob = weights / total (src/resampling.cpp:24,51)
@@ -2037,8 +2045,13 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
     if (t == 0 && g.state_est) { for (int d = 0; d < D; d++) { double s0 = 0.0; s0 += sep[d]; g.state_est[(long long)fi * (T + 1) * D + d] = s0; } }
     double* xa = XA; double* xb = XB;
     long long ph[6] = {0, 0, 0, 0, 0, 0};
+#ifdef BSSM_DEV_STAMPS
     const bool prof = (g.phase_cycles != nullptr) && fi == 0 && t == 0;
 #define PH(k) { if (prof) { const long long c_ = clock64(); ph[k] += c_ - pc; pc = c_; } }
+#else
+    const bool prof = false;
+#define PH(k) { (void)pc; }
+#endif
     int ktrans = 0, prev_t = 0;
     for (int i = 1; i <= T; i++) {                                                        // :123
         const int ot = g.obs_times ? g.obs_times[i - 1] : i;
