@@ -379,3 +379,22 @@ def test_r_seeded_bootstrap_filter(B, ctx, oracle, ra, rf):
     # the stream is consumed in R's order: the initial particles are rnorm(N) right after set.seed
     assert (d["z_init"] == rnorm_vec(RRandom(1405), N)).all()
     np.testing.assert_allclose(res["particles_history"][0], d["z_init"], rtol=0, atol=0)
+
+
+def test_device_normals_recomputed_on_host(B, ctx, oracle):
+    """The device's Box-Muller pair (Philox block -> two uniforms -> sqrt(-2 log u1) (cos, sin)(2 pi u2), with the trimmed
+    log of csrc/rng.h) against the same formula in numpy on the oracle's restatement of Philox: agreement to a few ulp."""
+    seed, stream, call, n = 1405, 9, 3, 4096
+    d = np.empty(n)
+    from bayesssm_amd import _lib
+    _lib.check(_lib.load().bssm_dump_normals(ctx.handle, seed, stream, 2, call, n, d.ctypes.data_as(__import__("ctypes").c_void_p)))
+    k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+    skey = (stream & 0xFFFFFFFF) ^ (((stream >> 32) * 0x9E3779B9) & 0xFFFFFFFF)
+    want = np.empty(n)
+    for pair in range(n // 2):
+        r = oracle.philox4x32_10([pair, call, 2, skey], [k0, k1])
+        u1 = ((((int(r[1]) << 32) | int(r[0])) >> 11) + 0.5) * 2.0 ** -53
+        u2 = ((((int(r[3]) << 32) | int(r[2])) >> 11) + 0.5) * 2.0 ** -53
+        rad = np.sqrt(-2.0 * np.log(u1))
+        want[2 * pair], want[2 * pair + 1] = rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)
+    np.testing.assert_allclose(d, want, rtol=2e-14, atol=2e-15)

@@ -106,6 +106,73 @@ __global__ __launch_bounds__(1024) void k4(long long* out, const uint64_t* g, ui
     sink[t & 63] = s;
 }
 
+
+// candidates for the Box-Muller transcendental part (u in (0,1)): fdlibm-style log without special cases, sin/cos(2 pi u) by
+// quadrant reduction + the fdlibm kernels
+__device__ __forceinline__ double fast_log01(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t b = (uint64_t)__double_as_longlong(x);
+    int k = (int)(b >> 52) - 1023;
+    uint64_t m = b & 0x000FFFFFFFFFFFFFull;
+    // mantissa in [sqrt(2)/2, sqrt(2))
+    const bool up = m > 0x6A09E667F3BCDull;
+    k += up ? 1 : 0;
+    const double mm = __longlong_as_double((long long)(m | (up ? 0x3FE0000000000000ull : 0x3FF0000000000000ull)));
+    const double f = mm - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+__device__ __forceinline__ void fast_sincos2pi(double u, double& sn, double& cs)
+{
+    // angle = 2 pi u, u in (0,1): q = round(4u) quarter turns, r = u - q/4 in [-1/8, 1/8], t = 2 pi r in [-pi/4, pi/4]
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10,
+                 C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double q = rint(4.0 * u);
+    const double r = u - 0.25 * q;                       // exact
+    const double t = 6.283185307179586476925 * r;
+    const double z = t * t;
+    const double sp = t + t * z * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double cp = 1.0 - 0.5 * z + z * z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const int qi = (int)q & 3;
+    sn = (qi == 0) ? sp : (qi == 1) ? cp : (qi == 2) ? -sp : -cp;
+    cs = (qi == 0) ? cp : (qi == 1) ? -sp : (qi == 2) ? -cp : sp;
+}
+__global__ void k5(long long* out, const double* g, double* sink, double* err)
+{
+    const int t = threadIdx.x;
+    double x = 0.3 + 1e-3 * t + g[t];
+    long long c0, c1; int slot = 0;
+#define M5(body) { c0 = clock64(); for (int r = 0; r < 20; r++) { body; } c1 = clock64(); if (t == 0) out[slot] = (c1 - c0) / 20; slot++; }
+    double a = 0, b2 = 0;
+    M5(a += log(x); x = x * 0.999 + 1e-4)
+    M5(a += fast_log01(x); x = x * 0.999 + 1e-4)
+    double s_ = 0, c_ = 0;
+    M5(sincospi(2.0 * x, &s_, &c_); a += s_ + c_; x = x * 0.999 + 1e-4)
+    M5(fast_sincos2pi(x, s_, c_); a += s_ + c_; x = x * 0.999 + 1e-4)
+    // accuracy over a sweep of u
+    double e1 = 0, e2 = 0;
+    for (int i = 0; i < 4000; i++) {
+        const double u = (t * 4000 + i + 0.5) / (256.0 * 4000.0);
+        e1 = fmax(e1, fabs(fast_log01(u) - log(u)) / fabs(log(u) - 1e-300));
+        double s1, c1_, s2, c2; sincospi(2.0 * u, &s1, &c1_); fast_sincos2pi(u, s2, c2);
+        e2 = fmax(e2, fmax(fabs(s1 - s2), fabs(c1_ - c2)));
+    }
+    err[t] = e1; err[256 + t] = e2;
+    sink[t] = a + b2 + x;
+}
+
 int main()
 {
     long long* out; double *g, *sink;
@@ -135,5 +202,10 @@ int main()
         hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost);
         printf("walk_chain 10 links inside a 1024-thread workgroup, %s: %lld cycles\n", mode ? "all 16 waves walking" : "15 waves waiting at the barrier", h[0]);
     }
+    { double* err; hipMalloc(&err, 512 * 8); hipMemset(out, 0, 64 * 8);
+      hipLaunchKernelGGL(k5, dim3(1), dim3(256), 0, 0, out, g, sink, err); hipDeviceSynchronize();
+      hipMemcpy(h, out, 64 * 8, hipMemcpyDeviceToHost); double he[512]; hipMemcpy(he, err, 512 * 8, hipMemcpyDeviceToHost);
+      double e1 = 0, e2 = 0; for (int i = 0; i < 256; i++) { e1 = fmax(e1, he[i]); e2 = fmax(e2, he[256 + i]); }
+      printf("log %lld cycles, fast_log01 %lld; sincospi %lld, fast_sincos2pi %lld; max rel err log %.2e, max abs err sin/cos %.2e\n", h[0], h[1], h[2], h[3], e1, e2); }
     return 0;
 }
