@@ -175,7 +175,7 @@ def main():
             nbytes = KERNEL_BYTES.get(dom, 0.0) * N
             ach = nbytes / (kern[dom]["avg_us"] * 1e-6) / 1e9 if nbytes else 0.0
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
             if N == 1 << 20 and os.path.exists(tpath):
                 # fabric-side bytes per launch of this kernel, from committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
                 # see the file's "source"); not collected live
