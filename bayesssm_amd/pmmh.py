@@ -290,6 +290,11 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
       * as in the reference, `resample_algorithm` / `resample_fn` are validated but NOT forwarded to the
         main chain's filter calls (R/pmmh.R:403-415; tests/testthat/test-pmmh.R:404-466): the wrapper
         defaults (SISAR, stratified) apply, unless `pf_resample_algorithm` / `pf_resample_fn` are given.
+
+    Execution on one rank (extra keywords of this build): chains whose filters fit one workgroup (N <= 2048) advance in
+    lock-step, one kernel launch per iteration for all of them (`batch_chains=True`, bssm_pmmh_chains_batch); larger
+    filters run up to `chains_per_gpu` chains concurrently on separate HIP streams.  Either way a chain's draws are keyed
+    by (seed, chain index): results do not depend on the placement (tests/testthat/test-pmmh.R:499-503).
     """
     tune_control = tune_control or default_tune_control()
     y = np.asarray(y, dtype=np.float64)
