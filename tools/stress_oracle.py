@@ -4,9 +4,49 @@ import numpy as np, bayesssm_amd as b
 from oracle import oracle as orc
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
-ctx = b.Context(0, 8192, 1)
+sys.path.insert(0, 'tests')
+from test_gpu_sir import _simulate as sim_sir
+ctx = b.Context(0, 8192, 2)
 t0 = time.time(); cases = 0; bad = 0; worst = 0.0; refused = 0; reasons = {}
+def sir_case():
+    """SIR (Gillespie transition: both sides use their own restatement of the counter-based generator; resampling draws injected)."""
+    N = int(rng.choice([rng.integers(1, 30), rng.integers(30, 600), rng.integers(600, 4000)]))
+    T = int(rng.integers(1, 15))
+    alg = ["BPF", "APF"][int(rng.integers(0, 2))]
+    ra = ["SIS", "SISR", "SISAR"][int(rng.integers(0, 3))]
+    rf = ["stratified", "systematic", "multinomial"][int(rng.integers(0, 3))]
+    lam, gam = float(rng.uniform(0.2, 0.8)), float(rng.uniform(0.1, 0.4))
+    y = sim_sir(rng, T, lam=lam, gam=gam)
+    m = b.models.sir()
+    seed, stream = int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 2 ** 40))
+    ncall = 2 * T
+    ur = rng.random(ncall) if rf == "systematic" else rng.random((ncall, N))
+    kw = dict(resample_fn=rf, ctx=ctx, return_particles=False, seed=seed, stream=stream, draws={"u_res": ur}, lambda_=lam, gamma=gam)
+    fns = (m.init_fn, m.transition_fn, m.log_likelihood_fn)
+    r = (b.bootstrap_filter(y, N, *fns, resample_algorithm=ra, **kw) if alg == "BPF" else
+         b.auxiliary_filter(y, N, *fns, m.aux_log_likelihood_fn, resample_algorithm=ra, **kw))
+    ref = orc.pf_run("sir", [lam, gam, 500, 430, 70], y, N, None, None, ur, algorithm=alg, resample_algorithm=ra, resample_fn=rf,
+                     seed=seed, stream=stream)
+    return r, ref, ("sir", alg, N, T, ra, rf, seed, stream)
+
+
 while time.time() - t0 < budget:
+    if rng.random() < 0.25:
+        try:
+            r, ref, tag = sir_case()
+        except Exception as e:
+            cases += 1; refused += 1; reasons[str(e)[:60]] = reasons.get(str(e)[:60], 0) + 1; continue
+        ok = r["_extras"]["early_return_step"] == ref["early_return_step"]
+        if np.isfinite(ref["loglike"]):
+            rel = abs(r["loglike"] - ref["loglike"]) / max(abs(ref["loglike"]), 1e-300); worst = max(worst, rel); ok &= rel <= 1e-6 or abs(r["loglike"] - ref["loglike"]) < 1e-9
+        else:
+            ok &= r["loglike"] == ref["loglike"]
+        ok &= np.allclose(r["ess"], ref["ess"], rtol=1e-6) and np.allclose(r["state_est"], ref["state_est"], rtol=1e-6, atol=1e-8)
+        ok &= bool((r["_extras"]["resampled"] == ref["resampled"]).all())
+        if not ok:
+            bad += 1; print("MISMATCH", tag, r["loglike"], ref["loglike"], flush=True)
+        cases += 1
+        continue
     model = ["lg", "ar1sin"][int(rng.integers(0, 2))]
     alg = ["BPF", "APF", "RMPF"][int(rng.integers(0, 3))]
     N = int(rng.choice([rng.integers(1, 30), rng.integers(30, 600), rng.integers(600, 6000)]))
