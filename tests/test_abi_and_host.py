@@ -160,3 +160,23 @@ def test_r_compatible_rng():
     # u_i = (i + U)/5 = .053 .253 .453 .653 .853 against cum = .1 .6 .7 .85 1   (src/resampling.cpp:55-63)
     from oracle import oracle as orc
     assert orc.resample_systematic(5, [0.1, 0.5, 0.1, 0.15, 0.15], RRandom(1).unif_rand()).tolist() == [1, 2, 2, 3, 5]
+
+
+def test_readme_series_regression():
+    """The README's data set regenerated with the R-compatible generator (README.md:97-114: set.seed(1405) and its rnorm calls, in
+    order).  Regression lock on this build's values; they follow from the generator pinned above, not from a run of R."""
+    from bayesssm_amd.rrng import RRandom, readme_series, r_seeded_draws
+    x, y = readme_series()
+    assert x.shape == (21,) and y.shape == (20,)
+    np.testing.assert_allclose(x[:3], [0.2725, 0.8444, 2.2314], atol=5e-4)
+    np.testing.assert_allclose(y[:3], [0.4135, 2.5377, 2.2431], atol=5e-4)
+    # 41 normals consumed = 82 uniforms: the stream position after the data simulation
+    g = RRandom(1405); g.runif(82)
+    h = RRandom(1405); [h.norm_rand() for _ in range(41)]
+    assert g.unif_rand() == h.unif_rand()
+    # draw bookkeeping of the seeded filter mode: sizes follow the resample decisions
+    d = r_seeded_draws(7, 5, 10, "stratified", [True, False, True, True, False])
+    assert d["z_init"].shape == (10,) and d["z_trans"].shape == (5, 10) and d["u_res"].shape == (5, 10)
+    assert (d["u_res"][3:] == 0).all() and (d["u_res"][:3] > 0).all()
+    d1 = r_seeded_draws(7, 5, 10, "systematic", [True] * 5, obs_times=[1, 3, 3, 4, 6])
+    assert d1["z_trans"].shape == (6, 10) and d1["u_res"].shape == (5,)
