@@ -5,6 +5,7 @@ built, cannot be loaded, or no MI355X is visible, calls fail loudly.
 """
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (BAYESSSM_AMD_LIB: load another build of the same library -- used by dev A/B runs of two builds on one GPU box)
@@ -166,6 +167,18 @@ class Context:
         if self._h:
             load().bssm_ctx_destroy(self._h)
             self._h = None
+            self.max_particles = 0          # a stale reference now fails the capacity check with a clear message
+            self.max_dim = 0
+
+    def require(self, num_particles, dim=1):
+        """An explicitly passed context is never swapped for another one behind the caller's back (a worker thread's
+        context must stay that thread's): too small or closed => error."""
+        if not self._h:
+            raise BssmError(ERR_ARG, "bayesssm_amd: this Context has been closed")
+        if self.max_particles < num_particles or self.max_dim < dim:
+            raise BssmError(ERR_CAPACITY, "bayesssm_amd: the Context holds %d particles of dimension %d; %d of dimension %d "
+                            "requested (create a larger Context)" % (self.max_particles, self.max_dim, num_particles, dim))
+        return self
 
     def __del__(self):
         try:
@@ -175,19 +188,24 @@ class Context:
 
 
 _default_ctx = {}
+_default_retired = []          # outgrown default contexts stay alive: another thread may still hold one
+_default_lock = threading.Lock()
 
 
 def default_context(min_particles=1, device=None, dim=1):
-    """Lazily created per-device context, grown when a larger filter (or state dimension) is requested."""
+    """Lazily created per-device context for calls that pass none, grown when a larger filter (or state dimension) is
+    requested.  One stream and one workspace: callers that run filters from several threads give each thread its own
+    Context instead (pmmh(chains_per_gpu=...) does)."""
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0")) % max(load().bssm_device_count(), 1)
-    ctx = _default_ctx.get(device)
-    if ctx is None or ctx.max_particles < min_particles or ctx.max_dim < dim:
-        old_dim = ctx.max_dim if ctx is not None else 1
-        old_cap = ctx.max_particles if ctx is not None else 0
-        if ctx is not None:
-            ctx.close()
-        cap = max(1 << 16, 1 << (int(max(min_particles, old_cap)) - 1).bit_length())
-        ctx = Context(device, cap, max(dim, old_dim))
-        _default_ctx[device] = ctx
-    return ctx
+    with _default_lock:
+        ctx = _default_ctx.get(device)
+        if ctx is None or ctx.max_particles < min_particles or ctx.max_dim < dim:
+            old_dim = ctx.max_dim if ctx is not None else 1
+            old_cap = ctx.max_particles if ctx is not None else 0
+            if ctx is not None:
+                _default_retired.append(ctx)
+            cap = max(1 << 16, 1 << (int(max(min_particles, old_cap)) - 1).bit_length())
+            ctx = Context(device, cap, max(dim, old_dim))
+            _default_ctx[device] = ctx
+        return ctx

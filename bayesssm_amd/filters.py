@@ -52,9 +52,7 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
             raise ValueError("Assertion on 'obs_times' failed")                                  # assert_integerish :73
     theta = np.ascontiguousarray(theta, dtype=np.float64)
     dim = models.dim_of(model)
-    ctx = ctx or _lib.default_context(N, dim=dim)
-    if ctx.max_particles < N or ctx.max_dim < dim:
-        ctx = _lib.default_context(N, dim=dim)
+    ctx = ctx.require(N, dim) if ctx is not None else _lib.default_context(N, dim=dim)
     max_trans, max_res = noise_shape(algorithm, T, ot)
     state_est = np.zeros((T + 1, dim)) if dim > 1 else np.zeros(T + 1)
     ess = np.zeros(T + 1)
@@ -167,7 +165,7 @@ def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelih
     seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (F,)))
     streams = np.arange(F, dtype=np.uint64) if streams is None else \
         np.ascontiguousarray(np.broadcast_to(np.asarray(streams, dtype=np.uint64), (F,)))
-    ctx = ctx or _lib.default_context(N, dim=1)
+    ctx = ctx.require(1, 1) if ctx is not None else _lib.default_context(N, dim=1)
     ll = np.zeros(F)
     se = np.zeros((F, T + 1, dim)) if dim > 1 else np.zeros((F, T + 1))
     ess = np.zeros((F, T + 1))

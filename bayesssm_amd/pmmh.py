@@ -103,8 +103,13 @@ def pilot_run(pf, pilot_n, pilot_reps, pf_batch=None):
     given, returns all the repetitions' log-likelihoods from ONE batched launch (same values as pf(n, rep))."""
     lls = np.asarray(pf_batch(pilot_n, list(range(pilot_reps)))) if pf_batch is not None else \
         np.array([pf(pilot_n, rep) for rep in range(pilot_reps)])
-    variance_estimate = float(np.var(lls, ddof=1))
-    target_n = int(np.ceil(pilot_n * variance_estimate)) if np.isfinite(variance_estimate) else 1000
+    with np.errstate(invalid="ignore"):
+        variance_estimate = float(np.var(lls, ddof=1))
+    if not np.isfinite(variance_estimate):
+        # R: var() of a vector holding -Inf is NaN, ceiling / max / min propagate it, and the next filter call stops in
+        # assert_count(num_particles) (R/pmmh_tuning.R:54-57 -> R/particle_filter_core.R:33)
+        raise ValueError("Assertion on 'num_particles' failed: May not be NA.")
+    target_n = int(np.ceil(pilot_n * variance_estimate))
     target_n = min(max(target_n, 50), 1000)                                   # :55-57
     return {"variance_estimate": variance_estimate, "target_n": target_n, "pilot_loglikes": lls}
 
@@ -152,7 +157,7 @@ def run_pilot_chain(pf, pilot_m, pilot_n, pilot_reps, priors, proposal_sd, trans
         message(str(mean))
     pr_ = pilot_run(lambda n, rep: pf(mean, n, 10_000_000 + rep), pilot_n, pilot_reps,
                     (lambda n, reps: pf_batch(mean, n, [10_000_000 + r for r in reps])) if pf_batch is not None else None)
-    message("Using %d particles for PMMH:" % pr_["target_n"])                                  # :308
+    print("Using %d particles for PMMH:" % pr_["target_n"])                                    # message(), unconditional (:308)
     return {"pilot_theta_mean": mean, "pilot_theta_cov": cov, "target_n": pr_["target_n"],
             "pilot_theta_chain": chain, "pilot_loglike_chain": llc, "variance_estimate": pr_["variance_estimate"]}
 
@@ -194,9 +199,8 @@ def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov
     """One chain of R/pmmh.R:403-415,422-500 on this process's GPU (bssm_pmmh_chain)."""
     y = np.ascontiguousarray(y, dtype=np.float64)
     T = y.size
-    ctx = ctx or _lib.default_context(num_particles)
-    if ctx.max_particles < num_particles:
-        ctx = _lib.default_context(num_particles)
+    dim = models.dim_of(model)
+    ctx = ctx.require(num_particles, dim) if ctx is not None else _lib.default_context(num_particles, dim=dim)
     ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
     algorithm = "APF" if pf_wrapper is auxiliary_filter else "BPF"
     ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None   # noqa: E731
@@ -206,9 +210,6 @@ def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov
     pk = np.ascontiguousarray([_lib.PRIOR[p.kind] for p in priors], dtype=np.int32)
     pa = np.ascontiguousarray([p.a for p in priors], dtype=np.float64)
     pb = np.ascontiguousarray([p.b for p in priors], dtype=np.float64)
-    dim = models.dim_of(model)
-    if ctx.max_dim < dim:
-        ctx = _lib.default_context(num_particles, dim=dim)
     consts = np.ascontiguousarray(list(init_theta) + list(model_constants or ()), dtype=np.float64)
     pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
                        _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, ptr(consts), int(consts.size),
@@ -241,7 +242,7 @@ def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, prop
     chain index -- bit for bit."""
     y = np.ascontiguousarray(y, dtype=np.float64)
     T, K = y.size, len(chain_indices)
-    ctx = ctx or _lib.default_context(num_particles)
+    ctx = ctx.require(1, 1) if ctx is not None else _lib.default_context(num_particles)
     ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
     ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None   # noqa: E731
     tr = np.ascontiguousarray([_lib.TRANSFORM[t] for t in transform], dtype=np.int32)
@@ -432,8 +433,11 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     conc = max(1, min(conc, len(mine)))
     ctxs = []
     if conc > 1:
-        cap = int(num_particles) if num_particles is not None else 1024
-        ctxs = [_lib.Context(_lib.default_context(1).device, max(cap, 1024), models.dim_of(model)) for _ in range(conc)]
+        # every worker thread owns one context for the whole call, sized for the largest filter it can be asked to run:
+        # the pilot's (pilot_n) and the main chain's (num_particles, or the pilot's target_n <= 1000)
+        cap = max(int(num_particles) if num_particles is not None else 1000,
+                  int(tune_control["pilot_n"]) if use_pilot else 0, 1024)
+        ctxs = [_lib.Context(_lib.default_context(1).device, cap, models.dim_of(model)) for _ in range(conc)]
 
     def run_pool(fn, items):
         """fn(item, ctx) over items, `conc` at a time, each worker holding one context."""

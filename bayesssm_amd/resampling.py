@@ -29,9 +29,7 @@ def _resample(kind, n, weights, U, ctx, return_cum=False, return_stats=False):
     w = np.ascontiguousarray(weights, dtype=np.float64)
     n = int(n)
     nw = int(w.size)
-    ctx = ctx or _lib.default_context(max(n, nw))
-    if ctx.max_particles < max(n, nw):
-        ctx = _lib.default_context(max(n, nw))
+    ctx = ctx.require(max(n, nw), 1) if ctx is not None else _lib.default_context(max(n, nw))
     U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1)
     need = 1 if kind == "systematic" else n
     if U.size < need:

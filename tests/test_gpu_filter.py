@@ -274,6 +274,34 @@ def test_pmmh_concurrent_chains_match_sequential(B, ctx):
         assert (a["theta_chain"][k] == b2["theta_chain"][k]).all()
 
 
+def test_pmmh_concurrent_pilots_keep_their_own_context(B, ctx):
+    """Pilot filters larger than the batched kernel's limit (pilot_n > 2048) with chains running concurrently: every
+    worker thread keeps its own context (sized for the pilot), so the result equals the one-chain-at-a-time run bit for
+    bit; an explicitly passed context that is too small is an error, never a silent swap."""
+    import warnings
+    rng = np.random.default_rng(4)
+    ys = _simulate(rng, 20)
+    m = B.models.linear_gaussian()
+    kw = dict(pf_wrapper=B.bootstrap_filter, y=ys, m=30, init_fn=m.init_fn, transition_fn=m.transition_fn,
+              log_likelihood_fn=m.log_likelihood_fn,
+              log_priors={"phi": B.prior_normal(0, 1), "sigma_x": B.prior_exponential(1), "sigma_y": B.prior_exponential(1)},
+              pilot_init_params=[{"phi": 0.6 + 0.1 * c, "sigma_x": 1.0, "sigma_y": 1.0} for c in range(3)],
+              burn_in=5, num_chains=3, seed=7, param_transform={"phi": "identity", "sigma_x": "log", "sigma_y": "log"},
+              tune_control=B.default_tune_control(pilot_n=3000, pilot_m=24, pilot_burn_in=4, pilot_reps=6))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = B.pmmh(chains_per_gpu=1, **kw)
+        b2 = B.pmmh(chains_per_gpu=3, **kw)
+    for k in ("chain", "phi", "sigma_x", "sigma_y"):
+        assert (a["theta_chain"][k] == b2["theta_chain"][k]).all()
+    small = B.Context(0, 1024, 1)
+    with pytest.raises(Exception, match="Context holds 1024"):
+        B.bootstrap_filter(ys, 5000, m.init_fn, m.transition_fn, m.log_likelihood_fn, ctx=small, phi=0.8, sigma_x=1.0, sigma_y=1.0)
+    small.close()
+    with pytest.raises(Exception, match="closed"):
+        B.bootstrap_filter(ys, 100, m.init_fn, m.transition_fn, m.log_likelihood_fn, ctx=small, phi=0.8, sigma_x=1.0, sigma_y=1.0)
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 63, 65, 257, 2047, 2049, 4099])
 def test_ragged_particle_counts(B, ctx, oracle, N):
     """Odd / tiny / block-straddling particle counts (the reference's tests run N = 20..100)."""
