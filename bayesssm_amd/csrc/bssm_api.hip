@@ -47,6 +47,7 @@ struct bssm_ctx {
     SideList* side = nullptr;
     uint64_t* cin = nullptr;
     DevState* st = nullptr;
+    unsigned long long* gmax_cur = nullptr;   // slot of the grid-wide max(log-weights) of the weight evaluation in flight
     // growable buffers
     std::map<std::string, std::pair<void*, size_t>> pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -269,6 +270,7 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     const int lim = g_debug_lim > 0 ? g_debug_lim : rec_window(r.nw);
     const size_t shm = (size_t)B * sizeof(BlockRec);
     FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
+    f.gmax = r.d_lw ? c->gmax_cur : nullptr;
     f.ain_out = c->ain_w; f.plan = r.plan; f.N = r.nw; f.obs_i = r.obs_i; f.resample_algorithm = r.resample_algorithm;
     f.threshold = r.threshold; f.ess_out = r.d_ess; f.llh_out = r.d_llh; f.resampled_out = r.d_resampled;
     if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f);
@@ -452,12 +454,12 @@ template <int MODEL>
 static void launch_step(bssm_ctx* c, bool trans, int weight, bool subaux, double* x, long long N, int B,
                         const ModelPar& par, double y, const NoiseSrc& ns)
 {
-#define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st
+#define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur
     if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step<trans+weight>", (k_step<MODEL, true, 1, false>), B, NTS, 0, STEP_ARGS);
     else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step<trans+weight-aux>", (k_step<MODEL, true, 1, true>), B, NTS, 0, STEP_ARGS);
     else if (trans && weight == 0) LAUNCH(c, "k_step<trans>", (k_step<MODEL, true, 0, false>), B, NTS, 0, STEP_ARGS);
     else if (!trans && weight == 2) {
-        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NTS, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st);
+        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NTS, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur);
     }
 #undef STEP_ARGS
 }
@@ -465,7 +467,7 @@ static void launch_step(bssm_ctx* c, bool trans, int weight, bool subaux, double
 static void launch_step_sir(bssm_ctx* c, bool trans, int weight, bool subaux, double* x, long long N, int B,
                             const ModelPar& par, double y, const NoiseSrc& ns)
 {
-#define SIR_ARGS(LW) x, x, LW, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq
+#define SIR_ARGS(LW) x, x, LW, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->gmax_cur
     if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step_sir<trans+weight>", (k_step_sir<true, 1, false>), B, NTS, 0, SIR_ARGS(c->lw));
     else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step_sir<trans+weight-aux>", (k_step_sir<true, 1, true>), B, NTS, 0, SIR_ARGS(c->lw));
     else if (trans && weight == 0) LAUNCH(c, "k_step_sir<trans>", (k_step_sir<true, 0, false>), B, NTS, 0, SIR_ARGS(c->lw));
@@ -548,6 +550,12 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         HIPCHK(hipMemcpyAsync(d_umv, cfg->u_move, (size_t)T * N * 8, hipMemcpyHostToDevice, c->stream));
     }
     if (cfg->u_res && max_res > 0) { if ((rc = pool_get(c, "ur", (size_t)max_res * u_stride * 8, &d_ur))) return rc; HIPCHK(hipMemcpyAsync(d_ur, cfg->u_res, (size_t)max_res * u_stride * 8, hipMemcpyHostToDevice, c->stream)); }
+    void* d_gmax;                                        // one slot per weight evaluation (two per observation in the auxiliary filter)
+    const size_t n_gmax = (size_t)2 * T + 2, gm_words = (size_t)GM_SLOTS * GM_STRIDE;
+    if ((rc = pool_get(c, "gmax", n_gmax * gm_words * 8, &d_gmax))) return rc;
+    HIPCHK(hipMemsetAsync(d_gmax, 0, n_gmax * gm_words * 8, c->stream));      // key 0 lies below every double's key
+    size_t wcall = 0;
+    auto next_gmax = [&]() { c->gmax_cur = (unsigned long long*)d_gmax + (wcall < n_gmax ? wcall : n_gmax - 1) * gm_words; wcall++; };
     HIPCHK(hipMemsetAsync(d_separt, 0, (size_t)(T + 1) * B * dim * 8, c->stream));
     HIPCHK(hipMemsetAsync(d_ess, 0, (size_t)(T + 1) * 8, c->stream));
     HIPCHK(hipMemsetAsync(d_llh, 0, (size_t)(T + 1) * 8, c->stream));
@@ -589,22 +597,26 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         // gap transitions; the last one is fused with the weight evaluation unless APF  (:125-136)
         for (int step = 1; step <= gap; step++) {
             const bool fuse_w = (!apf && step == gap);
+            if (fuse_w) next_gmax();
             launch_step_model(c, cfg->model, true, fuse_w ? 1 : 0, false, X0, N, B, par, yi, noise(ktrans));
             ktrans++;
         }
         if (apf) {                                                                        // :140-175
+            next_gmax();
             launch_step_model(c, cfg->model, false, 2, false, X0, N, B, par, yi, noise(0));
             r.d_lw = c->auxlw; r.plan = PLAN_AUX; r.check_degenerate = 0; r.obs_i = i;
             r.xsrc = X0; r.xdst = X1; r.auxsrc = c->auxlw; r.auxdst = c->auxg; r.se_part = nullptr;
             launch_scan_and_apply(c, r);
             std::swap(X0, X1);
+            next_gmax();
             launch_step_model(c, cfg->model, true, 1, true, X0, N, B, par, yi, noise(ktrans));   // :159-175
             ktrans++;
         } else if (gap <= 0) {
             // obs_times repeats a time: no transition, weights on the current particles
             NoiseSrc ns = noise(0);
-            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st);
-            else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st);
+            next_gmax();
+            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur);
+            else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur);
             else launch_step_sir(c, false, 1, false, X0, N, B, par, yi, ns);
         }
         double* se_row = separt + (size_t)i * B * dim;

@@ -272,6 +272,21 @@ struct Sir {
     }
 };
 
+// Order-preserving map double -> uint64 (for an atomic max over doubles): x < y  <=>  key(x) < key(y); 0 is below every key.
+__device__ __forceinline__ unsigned long long f64_key(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
+// The grid maximum is kept in GM_SLOTS partial maxima on cache lines of their own (block b adds to slot b % GM_SLOTS): 512
+// atomics on ONE address serialise at the memory side (~5 ns each: the step kernel ran 2.5 us longer), 32 per line do not.
+constexpr int GM_SLOTS = 16, GM_STRIDE = 16;       // slots, and their spacing in uint64 (128 B)
+
 struct NoiseSrc {
     const double* arr;     // parity mode: N draws for this call; nullptr => generator
     PhiloxKey key;
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
                                               double* __restrict__ lw, const double* __restrict__ auxg,
                                               long long N, ModelPar par, double y, NoiseSrc ns,
                                               double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq,
-                                              const DevState* __restrict__ st)
+                                              const DevState* __restrict__ st, unsigned long long* __restrict__ gmax)
 {
     // (no early return on st->dead here: a dependent read of the run state in front of the particle loads would
     //  cost every launch a memory round trip; propagating a dead run is harmless, its results are never read)
@@ -378,7 +393,9 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
         }
         s = block_sum_n<NTS / 64>(s, sh);
         q = block_sum_n<NTS / 64>(q, sh);
-        if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; }
+        // max(log_weights) over the whole grid (R/particle_filter_core.R:204) by one atomic per block: the next kernel reads
+        // it with one load instead of reducing the B block maxima again in every workgroup
+        if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; atomicMax(gmax + (blockIdx.x % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
     }
 }
 
@@ -387,7 +404,8 @@ template <bool TRANS, int WEIGHT, bool SUBAUX>
 __global__ __launch_bounds__(NTS) void k_step_sir(const double* xin, double* xout /* may alias xin */,
                                                   double* __restrict__ lw, const double* __restrict__ auxg,
                                                   long long N, ModelPar par, double y, NoiseSrc ns,
-                                                  double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq)
+                                                  double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq,
+                                                  unsigned long long* __restrict__ gmax)
 {
     __shared__ double sh[NTS / 64];
     const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
@@ -419,7 +437,7 @@ __global__ __launch_bounds__(NTS) void k_step_sir(const double* xin, double* xou
         }
         s = block_sum_n<NTS / 64>(s, sh);
         q = block_sum_n<NTS / 64>(q, sh);
-        if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; }
+        if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; atomicMax(gmax + (blockIdx.x % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
     }
 }
 
@@ -554,11 +572,9 @@ __device__ __forceinline__ uint64_t stepfn_apply(const StepFn& f, uint64_t s, bo
     return (f.mode == 1) ? f.K0 : out;
 }
 
-// A boundary step as plain data in LDS.  The serial part of a scan is a chain of these; run lane-to-lane through
-// v_readlane it cost ~600 cycles a link (scalar branches, VALU->SALU hazards).  walk_chain() instead has every lane of one
-// wave evaluate the SAME dependent sequence from LDS-broadcast constants (next link prefetched), with no data-dependent
-// branch: ~10 dependent VALU ops a link.  Links that are not "simple" (HARD, side entries, window misses) stop the chain;
-// the caller continues from there with the general loop.
+// A boundary step as plain data.  The serial part of a scan is a chain of these, evaluated branch-free (walk_chain_regs):
+// ~10 dependent VALU ops a link.  Links that are not "simple" (HARD, side entries, window misses) stop the chain; the caller
+// continues from there with the general loop.
 struct alignas(16) WalkFn { uint64_t K0, K1, K2, K3; uint64_t nref, range; int sh; int pad0, pad1, pad2; };   // 64 B
 // a link accepts state s  <=>  (s + nref) <u range      (nref = -(sref + wlo), range = whi - wlo + 1; range 0 = never)
 
@@ -576,33 +592,35 @@ __device__ __forceinline__ WalkFn walkfn_from(const StepFn& f, bool simple)
 
 __device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// Steps the leading acceptable links of wf[0..nent) from state s (wf needs nent + 1 slots).  Returns how many were stepped
-// (jd) and leaves the state sequence in sseq[0..jd] (sseq[j] = state before link j; s = sseq[jd]).
-__device__ __forceinline__ int walk_chain(const WalkFn* wf, uint64_t* sseq, int nent, uint64_t& s)
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int j)
 {
-    const uint4* p = reinterpret_cast<const uint4*>(wf);
-    uint4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
-    int jbad = nent;
-    uint64_t sv = s;
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, j), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), j);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// The same walk with the chain in REGISTERS: lane j of the wave holds link j.  The state travels in scalar registers
+// (wave-uniform); per link every lane evaluates ITS link on the current state and lane j's result is read back with
+// v_readlane (j is the loop counter, a scalar).  No LDS round trip per link: the LDS form above waited ~500 cycles a link for
+// its four 16-byte reads (profiles/r02_a_stage_stamps_typical_block.txt: 10 links in 5000 cycles).
+// Returns how many leading links accepted their state (jd); lane j < jd gets (my_s, my_out) = the state before / after its
+// link; s = the state before link jd.
+__device__ __forceinline__ int walk_chain_regs(const WalkFn& w, int nent, uint64_t& s, uint64_t& my_s, uint64_t& my_out)
+{
+    const int lane = threadIdx.x & 63;
+    uint64_t sv = readlane_u64(s, 0);
+    int j = 0;
 #pragma unroll 1
-    for (int j = 0; j < nent; j++) {      // NOT unrolled: this runs once per launch on a cold instruction cache; a compact body is fetched once
-        const uint4 b0 = p[4 * j + 4], b1 = p[4 * j + 5], b2 = p[4 * j + 6], b3 = p[4 * j + 7];     // next link
-        sseq[j] = sv;
-        const uint64_t K0 = mk64(a0.x, a0.y), K1 = mk64(a0.z, a0.w), K2 = mk64(a1.x, a1.y), K3 = mk64(a1.z, a1.w);
-        const bool bad = (sv + mk64(a2.x, a2.y)) >= mk64(a2.z, a2.w);
-        jbad = (bad && j < jbad) ? j : jbad;
+    for (; j < nent; j++) {
+        const bool bad = (sv + w.nref) >= w.range;
         const uint32_t lo = (uint32_t)sv;
-        const bool bit0 = (lo & 1u) != 0, bit1 = (lo & 2u) != 0;
-        const uint64_t k01 = bit0 ? K1 : K0, k23 = bit0 ? K3 : K2;
-        sv = ((sv & ~3ull) >> (a3.x & 63)) + (bit1 ? k23 : k01);
-        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+        const uint64_t k01 = (lo & 1u) ? w.K1 : w.K0, k23 = (lo & 1u) ? w.K3 : w.K2;
+        const uint64_t out = ((sv & ~3ull) >> (w.sh & 63)) + ((lo & 2u) ? k23 : k01);
+        if (__builtin_amdgcn_readlane((int)bad, j)) break;
+        if (lane == j) { my_s = sv; my_out = out; }
+        sv = readlane_u64(out, j);
     }
-    const int jd = __builtin_amdgcn_readfirstlane(jbad);
-    if (jd == nent) sseq[nent] = sv;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    s = sseq[jd];
-    return jd;
+    s = sv;
+    return j;
 }
 
 __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off)
@@ -616,13 +634,11 @@ struct SegSmem {
     Pure wagg[16]; int wflag[16]; int wnb[16]; Pure wcarry[17]; int wsegbase[17];
     Pure bnd_excl[MAXBND]; Rec bnd_rec[MAXBND]; int bnd_lane[MAXBND]; uint64_t bnd_ent[MAXBND];
     double bnd_terms[MAXBND][EL];    // the terms of every boundary lane (so a literal re-run never chases global memory)
-    WalkFn wf[MAXBND + 1];           // the boundary chain as data (walk_chain)
-    uint64_t sseq[MAXBND + 1];       // its state sequence
     uint64_t seg_start[MAXBND + 1];
     long long red_min[4][2], red_max[4][2];
     uint64_t seg1_base;
     uint64_t segbase[MAXBND + 1]; int smin[MAXBND + 1]; int smax[MAXBND + 1];
-    int nb; int fail; int first_bnd;
+    int nb; int fail; int first_bnd; int big;
     double sh4[16];
     double bcast;
 };
@@ -807,11 +823,8 @@ __device__ __forceinline__ bool block_resolve(SegSmem& sm, const BlockScan& bs, 
         if (lane < nb) { rec = sm.bnd_rec[lane]; ex = sm.bnd_excl[lane]; }
         const StepFn fn = stepfn_build(ex, rec);             // "PURE run + this boundary" folded into constants
         uint64_t s = cin, my_s = 0, my_out = 0;
-        if (lane < nb) sm.wf[lane] = walkfn_from(fn, true);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int j0 = walk_chain(sm.wf, sm.sseq, nb, s);
-        if (lane < j0) { my_s = sm.sseq[lane]; my_out = sm.sseq[lane + 1]; }
+        const WalkFn wfn = walkfn_from(fn, lane < nb);
+        const int j0 = walk_chain_regs(wfn, nb, s, my_s, my_out);
         for (int j = j0; j < nb; j++) {                      // what the chain could not take (HARD leaves, window misses)
             bool ok;
             uint64_t o = stepfn_apply(fn, s, ok);
@@ -935,6 +948,7 @@ __device__ __forceinline__ Rec pure_to_rec(const Pure& p, uint64_t base, long lo
 // the approximate block prefixes from the log-sum-exp partials instead of a separate pass.
 struct FromLw {
     const double* lw; double* w_out; const double* pm; const double* ps; const double* pq; int nb;
+    const unsigned long long* gmax;      // key of max(pm[0..nb)) left by the step kernel's atomics, or nullptr (then reduced here)
     double* ain_out;
     // per-observation bookkeeping that only needs the partials (R/particle_filter_core.R:189-218): every block
     // derives the same numbers; block 0 records them
@@ -980,21 +994,29 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
 #pragma unroll
             for (int k = 0; k < EL; k++) l8[k] = (j0 + k < nw) ? f.lw[j0 + k] : -INFINITY;
         }
-        // all three partial arrays are fetched up front (one memory round trip), then reduced
-        double pmv[MAXBL / NT], psv[MAXBL / NT], pqv[MAXBL / NT];
+        // Thread t holds the partials of the L consecutive blocks t L .. t L + L - 1 (L = nb / NT rounded up): all three
+        // arrays and the grid maximum are fetched up front (one memory round trip).
+        constexpr int KMAX = MAXBL / NT;
+        const int L = (f.nb + NT - 1) / NT;
+        double pmv[KMAX], psv[KMAX], pqv[KMAX];
 #pragma unroll
-        for (int k = 0; k < MAXBL / NT; k++) {
-            const int i = t + NT * k;
-            const bool in = i < f.nb;
+        for (int k = 0; k < KMAX; k++) {
+            const int i = t * L + k;
+            const bool in = (k < L) && (i < f.nb);
             pmv[k] = in ? f.pm[i] : -INFINITY; psv[k] = in ? f.ps[i] : 0.0; pqv[k] = in ? f.pq[i] : 0.0;
         }
-        // one block (nb == 1, finite max): M = pm[0], S = ps[0] exp(0) = ps[0], sq = pq[0] -- exactly what the reductions below
-        // return (they add zeros / take max with -inf), without their latency
-        const bool one = (MAXBL == NT) && (f.nb == 1) && (f.pm[0] > -INFINITY);
-        double m = -INFINITY;
+        double M;
+        if (f.gmax) {                             // every wave reduces the GM_SLOTS partial maxima itself: one load, no barrier
+            const unsigned long long kq = f.gmax[(t % GM_SLOTS) * GM_STRIDE];
+            M = wave_max(kq ? key_f64(kq) : -INFINITY);           // (key 0: no block added to that slot)
+        } else {
+            // one block (nb == 1, finite max): M = pm[0] -- exactly what the reduction returns (it takes max with -inf)
+            const bool one = (MAXBL == NT) && (f.nb == 1) && (f.pm[0] > -INFINITY);
+            double m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < MAXBL / NT; k++) m = fmax(m, pmv[k]);
-        const double M = one ? f.pm[0] : block_max(m, sm.sh4);
+            for (int k = 0; k < KMAX; k++) m = fmax(m, pmv[k]);
+            M = one ? f.pm[0] : block_max(m, sm.sh4);
+        }
         const bool degenerate = (f.plan == PLAN_PF) && (M < -1e8);       // all(log_weights < -1e8)  (:189-202)
         if (degenerate) {
             if (bidx == 0 && t == 0) {
@@ -1002,17 +1024,29 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
             }
             return;
         }
-        double se = 0.0, sq = 0.0;
+        // sum_b w = ps[b] exp(pm[b] - M) / S: this thread's slice, then ONE block scan gives the slice prefixes and S
+        double esv[KMAX];
+        double ts0 = 0.0, tq = 0.0;
 #pragma unroll
-        for (int k = 0; k < MAXBL / NT; k++) {
-            const int i = t + NT * k;
+        for (int k = 0; k < KMAX; k++) {
             double x = 0.0;
-            if (pmv[k] > -INFINITY) { const double ex = exp(pmv[k] - M); x = psv[k] * ex; sq += pqv[k] * ex * ex; }
-            es[i] = x; se += x;
+            if (pmv[k] > -INFINITY) { const double ex = exp(pmv[k] - M); x = psv[k] * ex; tq += pqv[k] * ex * ex; }
+            esv[k] = x; ts0 += x;
         }
-        double S;
-        if (one) { S = f.ps[0] * exp(f.pm[0] - M); sq = f.pq[0] * exp(f.pm[0] - M) * exp(f.pm[0] - M); __syncthreads(); }
-        else { S = block_sum(se, sm.sh4); sq = block_sum(sq, sm.sh4); }     // (block_sum syncs: es[] is complete)
+        double pre, S, sq;
+        {
+            const int lane = t & 63, wave = t >> 6;
+            const double inc = wave_incl_sum(ts0);
+            const double exc = dpp_f64<DPP_WAVE_SHR1, 0xf>(0.0, inc);        // lane 0 keeps 0
+            const double wq = wave_sum(tq);
+            __syncthreads();
+            if (lane == 63) { sm.sh4[wave] = inc; sm.sh4[8 + wave] = wq; }
+            __syncthreads();
+            pre = exc;
+            for (int i = 0; i < wave; i++) pre += sm.sh4[i];
+            S = (sm.sh4[0] + sm.sh4[1]) + (sm.sh4[2] + sm.sh4[3]);
+            sq = (sm.sh4[8] + sm.sh4[9]) + (sm.sh4[10] + sm.sh4[11]);
+        }
         int doit = 1;
         if (f.plan == PLAN_PF) {
             const double ess = 1.0 / (sq / (S * S));                                          // :211
@@ -1027,33 +1061,27 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
                 if (doit) { st->cur_call = st->res_calls; st->res_calls += 1; }
             }
         } else if (bidx == 0 && t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
-        double ts0 = 0.0;
-#pragma unroll
-        for (int k = 0; k < MAXBL / NT; k++) ts0 += es[t * (MAXBL / NT) + k];
-        double pre = one ? 0.0 : block_excl_scan(ts0, sm.sh4);
-        if (t == bidx / (MAXBL / NT)) {           // the one lane whose slice holds this block: one division
+        if (t == bidx / L) {                      // the one lane whose slice holds this block: one division
             double pp = pre;
-            for (int k = 0; k < bidx % (MAXBL / NT); k++) pp += es[t * (MAXBL / NT) + k];
+#pragma unroll
+            for (int k = 0; k < KMAX; k++) if (k < bidx % L) pp += esv[k];
             sm.bcast = pp / S;
         }
         if (bidx == nblk / 2) {                   // one (ordinary) block also publishes every block's prefix, for ain_p later;
                                                              // not block 0: that one already walks the exact-zero head
+            double pp = pre;
 #pragma unroll
-            for (int k = 0; k < MAXBL / NT; k++) {
-                const int i = t * (MAXBL / NT) + k;
-                if (i < f.nb) f.ain_out[i] = pre / S;
-                pre += es[i];
+            for (int k = 0; k < KMAX; k++) {
+                const int i = t * L + k;
+                if (k < L && i < f.nb) f.ain_out[i] = pp / S;
+                pp += esv[k];
             }
         }
         __syncthreads();
         a_in = sm.bcast;
         BSSM_STAMP(st, dbg, 2, 8, stamper);
-        double s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < EL; k++) {
-            const double x = (j0 + k < nw) ? exp(l8[k] - M) / S : 0.0;                         // :205-207
-            v[k] = x; s1 += x;
-        }
+        for (int k = 0; k < EL; k++) v[k] = (j0 + k < nw) ? exp(l8[k] - M) / S : 0.0;        // :205-207
         if (j0 + EL <= nw || (LIT && j0 < nw)) {             // (LIT: the partly filled lane stores its zero padding too -- the in-order pass reads whole lanes)
             double2* p2 = reinterpret_cast<double2*>(f.w_out + j0);
 #pragma unroll
@@ -1063,8 +1091,9 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
             for (int k = 0; k < EL; k++) if (j0 + k < nw) f.w_out[j0 + k] = v[k];
         }
         if (!doit) return;                                   // SIS / SISAR without a resample: weights are all that is needed
-        s1 = block_sum(s1, sm.sh4);
-        if (!isfinite(s1)) {                                 // NaN/Inf log-weights: the scan stands down
+        // NaN/Inf log-weights: the scan stands down.  (lw <= M, so every exp(lw - M) / S is finite unless S or M is not: a NaN
+        // log-weight makes its block's sum NaN, +Inf makes M +Inf, all -Inf leaves S == 0 -- no pass over the weights needed)
+        if (!(S > 0.0) || !isfinite(S) || !isfinite(M)) {
             if (t == 0) atomicOr(&st->flags, FLAG_NONFINITE);
             return;
         }
@@ -1193,7 +1222,7 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
 {
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT];
-    __shared__ double es[FROM_LW ? MAXB : 1];
+    __shared__ double es[1];
     local_block<MODE, FROM_LW, MAXB>(sm, tin, es, (int)blockIdx.x, (int)gridDim.x, w, nw, ain, lim, brec, side, st, f);
 }
 
@@ -1281,8 +1310,6 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
     __shared__ SegSmem sm;
     __shared__ uint64_t final_state;
     __shared__ __attribute__((aligned(16))) SideEntry sideC[64];
-    __shared__ WalkFn wfr[65];
-    __shared__ uint64_t sseq[65];
     const int t = threadIdx.x;
     // run-state words are fetched together with the block records (checked after the staging barrier)
     const int s_dead = st->dead, s_do = st->do_resample, dbg0 = st->debug_stop; (void)dbg0;
@@ -1370,15 +1397,14 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
             uint64_t s = 0, my_in = 0, my_out = 0;
             const bool special = (bidx >= 0) && (slow || nside == 1);
             const StepFn fn = stepfn_build(ex, pr);          // "PURE run + this block's record" folded into constants
-            if (lane < nent) wfr[lane] = walkfn_from(fn, bidx >= 0 && !special);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            const WalkFn wfn = walkfn_from(fn, lane < nent && bidx >= 0 && !special);
             BSSM_STAMP(st, dbg0, MODE, 10, t == 0 && fn.mode >= 0);
             // (MODE_P: nobody needs the state after the last block -- skip its link, usually the slow one)
-            const int blast = __builtin_amdgcn_readlane(bidx, nent - 1);
-            const int nstep = (MODE == MODE_P && blast == B - 1) ? nent - 1 : nent;
-            const int j0 = walk_chain(wfr, sseq, nstep, s);
-            if (lane < j0) { my_in = pure_step(ex, sseq[lane]); my_out = sseq[lane + 1]; }
+            const int blast = __builtin_amdgcn_readlane(bidx, nent > 0 ? nent - 1 : 0);
+            const int nstep = (MODE == MODE_P && nent > 0 && blast == B - 1) ? nent - 1 : nent;
+            uint64_t my_s0 = 0;
+            const int j0 = walk_chain_regs(wfn, nstep, s, my_s0, my_out);
+            if (lane < j0) my_in = pure_step(ex, my_s0);
 #ifdef BSSM_DEV_STAMPS
             if (dbg0 == 99 && t == 0) { st->stamps[MODE][12] = j0; st->stamps[MODE][13] = clock64(); }
 #endif
@@ -1534,24 +1560,30 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
     const double total = b2d(st->total_bits);
     double v[EL];
     load_terms<MODE_W>(a.w, a.nw, 1.0, b0 + (long long)t * EL, v);
-    // this lane's own particles travel with its terms: the common expansion path stores them straight to the
-    // outputs their elements own, with no dependent gather
+    // The particles travel with the elements that own them: the common expansion path stores them straight to the
+    // outputs their elements own, with no dependent gather.  For the expansion a lane holds the elements
+    // wave * 64 * EL + 64 k + lane (k = 0..EL-1) -- lane-interleaved, NOT the EL consecutive elements its terms cover:
+    // neighbouring lanes then write neighbouring outputs.  (With consecutive elements per lane the lanes' output
+    // positions were ~EL apart and the 8-byte LDS stores ran into 8-way bank conflicts: that stage took 9k of the kernel's
+    // 19k cycles, profiles/r02_a_stage_stamps_typical_block.txt.)
+    const int ebase = (t >> 6) * (64 * EL) + (t & 63);       // element (within the block) of k = 0
     double xs0[EL], xs1[EL], axs[EL];
 #pragma unroll
     for (int k = 0; k < EL; k++) { xs0[k] = 0.0; xs1[k] = 0.0; axs[k] = 0.0; }
     if (KIND != 2) {
-        if (a.xdst) {
-            load_terms<MODE_W>(a.xsrc, a.nw, 1.0, b0 + (long long)t * EL, xs0);
-            if (a.dim > 1) {
 #pragma unroll
-                for (int k = 0; k < EL; k++) { const long long j = b0 + (long long)t * EL + k; xs1[k] = (j < a.nw) ? a.xsrc[a.xstride + j] : 0.0; }
+        for (int k = 0; k < EL; k++) {
+            const long long j = b0 + ebase + 64 * k;
+            if (j < a.nw) {
+                if (a.xdst) { xs0[k] = a.xsrc[j]; if (a.dim > 1) xs1[k] = a.xsrc[a.xstride + j]; }
+                if (a.auxdst) axs[k] = a.auxsrc[j];
             }
         }
-        if (a.auxdst) load_terms<MODE_W>(a.auxsrc, a.nw, 1.0, b0 + (long long)t * EL, axs);
     }
     const double a_in_p = a.ain_p[bidx];
     const uint64_t cinb = a.cin[bidx];
     if (s_dead || !s_do || s_flags) return;
+    if (t == 0) sm.big = 0;
     // the uniform(s) of this resample call (systematic: one draw; computed here, under the load latency)
     UniformSrc us;
     us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
@@ -1598,31 +1630,35 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
     }
     if (KIND == 2) return;                                            // multinomial: k_multinomial searches cum_out
     BSSM_STAMP(st, dbg, 3, 4, stamper);
-    if (t == 0) {
-        int tb = 0;
-        if (bidx > 0) {
-            const double cprev = b2d(cinb);
-            tb = (KIND == 1) ? count_le_systematic(cprev, a.n, Usys) : count_le_stratified(cprev, a.n, us);
-        }
-        Tbegin = tb;
+    // Outputs owned before this lane's first element: T of the lane's own exact incoming state (every lane evaluates it
+    // itself -- no LDS hand-off from the neighbouring lane, and the check below is complete before the barrier).
+    int tprev;
+    {
+        const long long jprev = b0 + (long long)t * EL - 1;
+        if (jprev < 0) tprev = 0;
+        else if (jprev >= a.nw - 1) tprev = a.n;                      // the clamp of src/resampling.cpp:33,59 already applied
+        else tprev = (KIND == 1) ? count_le_systematic(b2d(ent), a.n, Usys) : count_le_stratified(b2d(ent), a.n, us);
     }
-    __syncthreads();
-    const int Tb = Tbegin, Te = Tl[EB - 1];
-    int* anc = a.anc_out ? a.anc_out + (long long)call * a.anc_stride : nullptr;
-    const double invN = 1.0 / (double)a.n;
-    double acc0 = 0.0, acc1 = 0.0;
-    // Expansion.  Each element owns the outputs [T_prev, T) (src/resampling.cpp:30-37).  Common case (no element
-    // owns more than 64 outputs): every lane stores its own elements' particles straight to the outputs they own --
-    // consecutive lanes own consecutive output ranges, and nothing has to be gathered.  Otherwise (degenerate
-    // weights: a few particles own almost everything): all lanes share the work through a binary search in the counts.
-    int tprev = (t == 0) ? Tb : Tl[t * EL - 1];
     int maxcnt = 0;
     {
         int p = tprev;
 #pragma unroll
         for (int k = 0; k < EL; k++) { maxcnt = (Tk[k] - p) > maxcnt ? (Tk[k] - p) : maxcnt; p = Tk[k]; }
     }
-    const int any_big = __syncthreads_or(maxcnt > 64);
+    if (maxcnt > 64) sm.big = 1;                                      // (cleared at entry; barriers in between)
+    if (t == 0) Tbegin = tprev;
+    __syncthreads();
+    BSSM_STAMP(st, dbg, 3, 7, stamper);
+    const int Tb = Tbegin, Te = Tl[EB - 1];
+    int* anc = a.anc_out ? a.anc_out + (long long)call * a.anc_stride : nullptr;
+    const double invN = 1.0 / (double)a.n;
+    double acc0 = 0.0, acc1 = 0.0;
+    // Expansion.  Each element owns the outputs [T_prev, T) (src/resampling.cpp:30-37).  Common case (no element
+    // owns more than 64 outputs): every lane stores its elements' particles straight to the outputs they own --
+    // neighbouring lanes own neighbouring output ranges, and nothing has to be gathered.  Otherwise (degenerate
+    // weights: a few particles own almost everything): all lanes share the work through a binary search in the counts.
+    const int any_big = sm.big;
+    BSSM_STAMP(st, dbg, 3, 8, stamper);
     if (!any_big) {
         // Scattered 8-byte stores cost the CU one address per lane (64 cache lines per wave instruction): with the
         // particles going straight to HBM that address traffic, not the bytes, bounded this stage.  Plain case
@@ -1632,24 +1668,30 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         const bool stage = (lx != nullptr) && a.xdst && !anc && need <= nstage && (Te - Tb) <= CAPX;
         double* lx1 = lx + CAPX;                                   // second state component
         double* lxa = lx + (a.dim > 1 ? 2 : 1) * CAPX;             // auxiliary log-weights
-        int p = tprev;
-        if (stage) {
+        int Tp[EL], Ts[EL];                                        // all the counts first: one LDS round trip, not EL
 #pragma unroll
-            for (int k = 0; k < EL; k++) {
-                const int T = Tk[k];
-                for (int i = p; i < T; i++) {
-                    lx[i - Tb] = xs0[k];
-                    if (a.dim > 1) lx1[i - Tb] = xs1[k];
-                    if (a.auxdst) lxa[i - Tb] = axs[k];
+        for (int k = 0; k < EL; k++) { const int e = ebase + 64 * k; Ts[k] = Tl[e]; Tp[k] = (e == 0) ? Tb : Tl[e - 1]; }
+        if (stage) {
+            // one loop over "j-th output of every element" with the EL stores predicated, instead of EL short loops
+            // (a divergent loop trip costs two scalar branches and a dozen instructions)
+            int cmax = 0;
+#pragma unroll
+            for (int k = 0; k < EL; k++) { Ts[k] -= Tp[k]; Tp[k] -= Tb; cmax = Ts[k] > cmax ? Ts[k] : cmax; }     // counts, staging offsets
+            for (int j = 0; __any(j < cmax); j++) {
+#pragma unroll
+                for (int k = 0; k < EL; k++) {
+                    if (j < Ts[k]) {
+                        lx[Tp[k] + j] = xs0[k];
+                        if (a.dim > 1) lx1[Tp[k] + j] = xs1[k];
+                        if (a.auxdst) lxa[Tp[k] + j] = axs[k];
+                    }
                 }
-                p = T;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < EL; k++) {
-                const int T = Tk[k];
-                const long long src = b0 + (long long)t * EL + k;
-                for (int i = p; i < T; i++) {
+                const long long src = b0 + ebase + 64 * k;
+                for (int i = Tp[k]; i < Ts[k]; i++) {
                     if (anc) anc[i] = (int)(src + 1);                    // 1-based (src/resampling.cpp:36,62)
                     if (a.xdst) {
                         a.xdst[i] = xs0[k];
@@ -1657,18 +1699,25 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
                     }
                     if (a.auxdst) a.auxdst[i] = axs[k];
                 }
-                p = T;
             }
         }
         // the state estimate sums the block's outputs in output order, strided over the lanes (every path does)
+        BSSM_STAMP(st, dbg, 3, 9, stamper);
         if (a.xdst) {
             __syncthreads();
-            for (int i = Tb + t; i < Te; i += NT) {
-                if (stage) {
-                    const double x0 = lx[i - Tb]; a.xdst[i] = x0; acc0 += x0 * invN;
-                    if (a.dim > 1) { const double x1 = lx1[i - Tb]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
-                    if (a.auxdst) a.auxdst[i] = lxa[i - Tb];
-                } else {
+            BSSM_STAMP(st, dbg, 3, 10, stamper);
+            if (stage) {
+                // all the LDS reads first, then the stores (a read-store pair per trip waited ~450 cycles a trip)
+                constexpr int R = CAPX / NT;
+                double xv[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; xv[r] = (i < Te) ? lx[i - Tb] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; if (i < Te) { a.xdst[i] = xv[r]; acc0 += xv[r] * invN; } }
+                if (a.dim > 1) for (int i = Tb + t; i < Te; i += NT) { const double x1 = lx1[i - Tb]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
+                if (a.auxdst) for (int i = Tb + t; i < Te; i += NT) a.auxdst[i] = lxa[i - Tb];
+            } else {
+                for (int i = Tb + t; i < Te; i += NT) {
                     acc0 += a.xdst[i] * invN;
                     if (a.dim > 1) acc1 += a.xdst[a.xstride + i] * invN;
                 }
@@ -2074,7 +2123,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             step_emul<MODEL, false, 2>(sh16, xa, AUXLW, nullptr, N, par, yi, ns, &pm1, &ps1, &pq1);
             __syncthreads();
             FromLw fa;
-            fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.ain_out = &ainw1;
+            fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.gmax = nullptr; fa.ain_out = &ainw1;
             fa.plan = PLAN_AUX; fa.N = N; fa.obs_i = i; fa.resample_algorithm = g.resample_algorithm; fa.threshold = g.threshold;
             fa.ess_out = nullptr; fa.llh_out = nullptr; fa.resampled_out = nullptr;
             if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa);
@@ -2117,7 +2166,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         }
         if (t == 0) { sep[0] = 0.0; sep[1] = 0.0; }
         FromLw fl;
-        fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.ain_out = &ainw1;
+        fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.gmax = nullptr; fl.ain_out = &ainw1;
         fl.plan = PLAN_PF; fl.N = N; fl.obs_i = i; fl.resample_algorithm = g.resample_algorithm; fl.threshold = g.threshold;
         fl.ess_out = g.ess + (long long)fi * (T + 1); fl.llh_out = g.llh + (long long)fi * T; fl.resampled_out = nullptr;
         // normalise + loglik/ESS/decision + the exact sum(weights) of the block (:204-218, src/resampling.cpp:20-24)

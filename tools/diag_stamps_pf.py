@@ -19,6 +19,8 @@ for r in (0, 1): print('resolve', r, 'walk setup->loop start', st[r][10] - st[r]
 kw = st[2]
 print('k_weights block 100: start->prologue', kw[8]-kw[4], 'prologue->weights', kw[9]-kw[8], 'weights->scan', kw[10]-kw[9], 'scan->minmax', kw[11]-kw[10], 'total', kw[11]-kw[4])
 names = ["k_resolve<W>: start, plan, staged, chunk, scan, walk, sync, final", "k_resolve<P>", "k_weights/k_local block 100: [0]start [1]loaded [2]scan [3]minmax ... [8]prologue [9]weights", "k_apply block 100: start, load, scan, resolve, T, expand, se"]
+ap = st[3]
+print('k_apply block 100 expand detail: T->Tb sync', ap[7]-ap[4], 'any_big sync', ap[8]-ap[7], 'emission', ap[9]-ap[8], 'barrier', ap[10]-ap[9], 'store loop', ap[5]-ap[10])
 for r in range(4):
     row = [int(x) for x in st[r][:10]]
     if r < 2: print('   nb, B =', row[8], row[9]); row = row[:8]
