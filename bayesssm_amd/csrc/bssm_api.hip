@@ -43,8 +43,8 @@ struct bssm_ctx {
     double *x0 = nullptr, *x1 = nullptr, *lw = nullptr, *w = nullptr, *auxlw = nullptr, *auxg = nullptr, *cum = nullptr;
     // scan workspace
     double *pm = nullptr, *ps = nullptr, *pq = nullptr, *bsum = nullptr, *bsq = nullptr, *ain_w = nullptr, *ain_p = nullptr;
-    BlockRec* brec = nullptr;
-    SideList* side = nullptr;
+    BlockRec *brec = nullptr, *brec_p = nullptr;      // block records of the sum(w) pass / of the cumsum(w / total) pass
+    SideList *side = nullptr, *side_p = nullptr;
     uint64_t* cin = nullptr;
     DevState* st = nullptr;
     unsigned long long* gmax_cur = nullptr;   // slot of the grid-wide max(log-weights) of the weight evaluation in flight
@@ -132,15 +132,20 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
     A((void**)&c->cum, npad * 8);
     A((void**)&c->pm, MAXB * 8); A((void**)&c->ps, MAXB * 8); A((void**)&c->pq, MAXB * 8); A((void**)&c->bsum, MAXB * 8); A((void**)&c->bsq, MAXB * 8);
     A((void**)&c->ain_w, MAXB * 8); A((void**)&c->ain_p, MAXB * 8);
-    A((void**)&c->brec, MAXB * sizeof(BlockRec)); A((void**)&c->cin, MAXB * 8);
-    A((void**)&c->side, (size_t)B * sizeof(SideList));
+    A((void**)&c->brec, MAXB * sizeof(BlockRec)); A((void**)&c->brec_p, MAXB * sizeof(BlockRec)); A((void**)&c->cin, MAXB * 8);
+    A((void**)&c->side, (size_t)B * sizeof(SideList)); A((void**)&c->side_p, (size_t)B * sizeof(SideList));
     A((void**)&c->st, sizeof(DevState));
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<MODE_W>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXB * (int)sizeof(BlockRec));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<MODE_P>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXB * (int)sizeof(BlockRec));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    static_assert(sizeof(ResolveSmem) <= 3 * CAPX * sizeof(double), "the in-kernel resolve borrows k_apply's staging area");
     if (e != hipSuccess) {
         g_err = std::string("bssm_ctx_create: ") + hipGetErrorString(e);
         bssm_ctx_destroy(c);
@@ -156,7 +161,7 @@ extern "C" void bssm_ctx_destroy(bssm_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->x0, c->x1, c->lw, c->w, c->auxlw, c->auxg, c->cum, c->pm, c->ps, c->pq, c->bsum, c->bsq,
-                    c->ain_w, c->ain_p, c->brec, c->side, c->cin, c->st};
+                    c->ain_w, c->ain_p, c->brec, c->brec_p, c->side, c->side_p, c->cin, c->st};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->pool) if (kv.second.first) (void)hipFree(kv.second.first);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -182,6 +187,8 @@ static int g_debug_stop = 0;
 extern "C" void bssm_debug_set_stop(int stage) { g_debug_stop = stage; }
 // Test aid: override the validity window of the scan records (ulps).  A tiny window makes the per-lane
 // verification fail almost everywhere, which drives the literal fallbacks of the real kernels.
+static int g_inkernel_resolve = 1;      // dev knob (A/B): resolve inside the consuming kernels vs k_resolve launches
+extern "C" void bssm_debug_set_inkernel_resolve(int on) { g_inkernel_resolve = on; }
 static int g_stage = 1;                 // dev knob: LDS staging of k_apply's particle stores
 extern "C" void bssm_debug_set_stage(int on) { g_stage = on; }
 static int g_debug_lim = 0;
@@ -273,11 +280,20 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     f.gmax = r.d_lw ? c->gmax_cur : nullptr;
     f.ain_out = c->ain_w; f.plan = r.plan; f.N = r.nw; f.obs_i = r.obs_i; f.resample_algorithm = r.resample_algorithm;
     f.threshold = r.threshold; f.ess_out = r.d_ess; f.llh_out = r.d_llh; f.resampled_out = r.d_resampled;
-    if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f);
-    else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f);
-    LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
-    LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), B, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec, c->side, c->st, f);
-    LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
+    // B <= 2 NT: the consuming kernels resolve the pass before them in every workgroup (resolve_in_block); larger grids
+    // keep the single-workgroup k_resolve launches (a thread would have to hold more than two block records)
+    const bool inres = g_inkernel_resolve && B <= 2 * NT;
+    if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr);
+    else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr);
+    if (inres) {
+        LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p);
+    } else {
+        LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
+        LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), B, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec_p, c->side_p, c->st, f, nullptr, nullptr, nullptr);
+        LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec_p, c->side_p, c->cin, c->ain_w, c->ain_p, c->st);
+    }
+    const BlockRec* pb = inres ? c->brec_p : nullptr;
+    const SideList* psd = inres ? c->side_p : nullptr;
     ApplyArgs a;
     a.w = r.d_w; a.nw = r.nw; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = r.n;
     a.u_base = r.d_u; a.u_stride = r.u_stride; a.key = r.key;
@@ -287,11 +303,11 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     a.auxsrc = r.auxsrc; a.auxdst = r.auxdst; a.se_part = r.se_part;
     // LDS staging for the coalesced particle store: one array per thing carried to the outputs
     a.nstage = (g_stage && r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
-    const size_t xshm = (size_t)a.nstage * CAPX * sizeof(double);
-    if (r.kind == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>", k_apply<1>, B, NT, xshm, a, c->st);
-    else if (r.kind == BSSM_STRATIFIED) LAUNCH(c, "k_apply<stratified>", k_apply<0>, B, NT, xshm, a, c->st);
+    const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), inres ? sizeof(ResolveSmem) : (size_t)0);
+    if (r.kind == BSSM_SYSTEMATIC) { if (inres) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), B, NT, xshm, a, c->st, pb, psd); else LAUNCH(c, "k_apply<systematic>", (k_apply<1, false>), B, NT, xshm, a, c->st, pb, psd); }
+    else if (r.kind == BSSM_STRATIFIED) { if (inres) LAUNCH(c, "k_apply<stratified>(+resolve<P>)", (k_apply<0, true>), B, NT, xshm, a, c->st, pb, psd); else LAUNCH(c, "k_apply<stratified>", (k_apply<0, false>), B, NT, xshm, a, c->st, pb, psd); }
     else {
-        LAUNCH(c, "k_apply<cum>", k_apply<2>, B, NT, 0, a, c->st);
+        if (inres) LAUNCH(c, "k_apply<cum>(+resolve<P>)", (k_apply<2, true>), B, NT, xshm, a, c->st, pb, psd); else LAUNCH(c, "k_apply<cum>", (k_apply<2, false>), B, NT, xshm, a, c->st, pb, psd);
         const int Bo = (int)(((long long)r.n + EB - 1) / EB);
         LAUNCH(c, "k_multinomial", k_multinomial, Bo, NT, 0, a.cum_out, r.nw, r.n, a, c->st);
     }

@@ -946,6 +946,9 @@ __device__ __forceinline__ Rec pure_to_rec(const Pure& p, uint64_t base, long lo
 // FROM_LW (filter path, MODE_W): the kernel also IS the normalisation step -- it turns log-weights
 // into weights  w = exp(lw - max) / sum  (R/particle_filter_core.R:205-207), writes them, and derives
 // the approximate block prefixes from the log-sum-exp partials instead of a separate pass.
+// what a pass takes over from the pass before it when the consuming workgroup resolved that pass itself (resolve_in_block)
+struct PassIn { bool given; double total; double a_in; };
+
 struct FromLw {
     const double* lw; double* w_out; const double* pm; const double* ps; const double* pq; int nb;
     const unsigned long long* gmax;      // key of max(pm[0..nb)) left by the step kernel's atomics, or nullptr (then reduced here)
@@ -963,17 +966,17 @@ template <int MODE, bool FROM_LW, int MAXBL, bool LIT = false>
 __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, double* es /* [MAXBL], FROM_LW only */, const int bidx, const int nblk,
                                             const double* __restrict__ w, long long nw, const double* __restrict__ ain,
                                             int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
-                                            const FromLw& f)
+                                            const FromLw& f, const PassIn pin = PassIn{false, 1.0, 0.0})
 {
     const int t = threadIdx.x;
     const long long b0 = (long long)bidx * EB;
     // run-state words and this lane's terms are fetched together (one memory round trip, not two)
     const int s_dead = st->dead, s_do = st->do_resample, dbg = st->debug_stop;
     const uint32_t s_flags = st->flags;
-    const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
+    const double total = (MODE == MODE_P) ? (pin.given ? pin.total : b2d(st->total_bits)) : 1.0;
     double vraw[EL];
     if (!FROM_LW) load_terms<MODE_W>(w, nw, 1.0, b0 + (long long)t * EL, vraw);
-    const double a_in_pre = FROM_LW ? 0.0 : ain[bidx];
+    const double a_in_pre = FROM_LW ? 0.0 : (pin.given ? pin.a_in : ain[bidx]);
     if (s_dead || s_flags) return;
     if (!FROM_LW && !s_do) return;
     const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0)); (void)stamper;
@@ -1215,17 +1218,6 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
 }
 
 
-template <int MODE, bool FROM_LW>
-__global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long long nw, const double* __restrict__ ain,
-                                              int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
-                                              FromLw f)
-{
-    __shared__ SegSmem sm;
-    __shared__ uint64_t tin[NT];
-    __shared__ double es[1];
-    local_block<MODE, FROM_LW, MAXB>(sm, tin, es, (int)blockIdx.x, (int)gridDim.x, w, nw, ain, lim, brec, side, st, f);
-}
-
 // ---------------------------------------------------------------------------
 // k_resolve (one workgroup): exact incoming state cin[b] of every block.
 // Same scheme one level up: each thread owns CB consecutive block records; a
@@ -1294,6 +1286,222 @@ __device__ __forceinline__ uint64_t block_out_exact(const BlockRec& br, const Si
     const OutLit r = block_out_exact_nl<MODE>(&br, side, w, nw, total, b, in);
     lit += r.lit;
     return r.out;
+}
+
+// ---------------------------------------------------------------------------
+// resolve_in_block: the grid-level resolve, run by EVERY workgroup of the consuming kernel for itself (B <= 2 NT blocks).
+// The records of a pass are tiny (64 B a block) and the resolve is a latency chain, not work: as a launch of its own
+// (k_resolve, one workgroup) it cost 6.4-7.4 us per pass at N = 2^20 -- launch, staging the records in LDS, a 16-wave
+// scan, the boundary walk -- with the other 255 CUs idle.  Here each consumer workgroup loads the records it needs straight
+// into registers (two per thread), scans them with its own 4 waves and walks the boundary chain once, while its own
+// weight / particle loads are already in flight.
+// Returns the exact state after blocks [0, upto)   (upto == B in a MODE_W pass: total = sum(w), src/resampling.cpp:20).
+// Same scheme as k_resolve: a run of PURE blocks is a PURE chunk, anything else a boundary chunk; every PURE chunk verifies
+// that the exact state entering it lies inside its records' windows, otherwise one lane walks the blocks in order.
+// ---------------------------------------------------------------------------
+struct ResolveSmem {
+    BlockRec bnd[64];                // the records of the boundary chunks' blocks, in walk order
+    __attribute__((aligned(16))) SideEntry sideC[64];
+    uint64_t result;
+};
+
+template <int MODE>
+__device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& rs, const BlockRec* __restrict__ brec,
+                                                     const SideList* __restrict__ side, const int B, const int upto,
+                                                     const double* __restrict__ w, long long nw, double total, DevState* st,
+                                                     const bool count_stats)
+{
+    const int t = threadIdx.x;
+    if (upto <= 0) return 0ull;                        // (block-uniform)
+    const int dbg = st->debug_stop; (void)dbg;
+    const bool stamper = (t == 0 && blockIdx.x == 100); (void)stamper;
+    BSSM_STAMP(st, dbg, MODE, 0, stamper);
+    const int CB = (B + NT - 1) / NT;                  // blocks per thread: 1 or 2 (the caller guarantees B <= 2 NT)
+    const int c0 = t * CB, c1 = (c0 + CB < upto) ? c0 + CB : upto;
+    BlockRec r0, r1;
+    r0.prefix = rec_identity(0); r0.tail_from = NT; r0.nside = 0; r1 = r0;
+    if (c0 < c1) r0 = brec[c0];
+    if (c0 + 1 < c1) r1 = brec[c0 + 1];
+    // the last block of the range often carries one side entry (next to cum == 1.0 in a full pass): fetch it with the records
+    if (t >= NT - (int)(sizeof(SideEntry) / 16)) {
+        const int q = t - (NT - (int)(sizeof(SideEntry) / 16));
+        reinterpret_cast<uint4*>(&rs.sideC[63])[q] = reinterpret_cast<const uint4*>(&side[upto - 1].e[0])[q];
+    }
+    if (t == 0) sm.fail = 0;
+    // chunk record: PURE composite + validity window relative to the first block's base
+    bool isb = false;
+    Pure comp; comp.d0 = 0; comp.d1 = 0;
+    long long wlo = -(1ll << 40), whi = (1ll << 40);
+    uint64_t cbase = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int b = c0 + i;
+        if (b < c1 && !isb) {
+            const BlockRec& r = i ? r1 : r0;
+            if (r.prefix.kind != REC_PURE || r.tail_from < NT || r.nside > 0) isb = true;
+            else {
+                if (i == 0) cbase = r.prefix.base;
+                const long long m0 = (long long)(cbase + (uint64_t)comp.d0 - r.prefix.base);
+                const long long m1 = (long long)(cbase + 1 + (uint64_t)comp.d1 - r.prefix.base);
+                const long long mmin = m0 < m1 ? m0 : m1, mmax = m0 > m1 ? m0 : m1;
+                const long long lo = (long long)r.prefix.lo - mmin + 2, hi = (long long)r.prefix.hi - mmax - 2;
+                wlo = lo > wlo ? lo : wlo; whi = hi < whi ? hi : whi;
+                Pure p; p.d0 = (int64_t)(r.prefix.o[0] - r.prefix.base); p.d1 = (int64_t)(r.prefix.o[1] - (r.prefix.base + 1));
+                comp = pure_compose(comp, p);
+            }
+        }
+    }
+    if (c0 >= c1) { isb = false; comp.d0 = comp.d1 = 0; }     // lanes past the range: identity
+    BSSM_STAMP(st, dbg, MODE, 1, stamper && comp.d0 != 1);
+    int seg, nb; Pure lastseg;
+    const Pure exc = seg_excl_scan<NT / 64>(sm, comp, isb, seg, nb, lastseg);
+    if (isb && seg < MAXBND) {
+        sm.bnd_excl[seg] = exc; sm.bnd_lane[seg] = t;
+        if (seg * CB + CB <= 64) { rs.bnd[seg * CB] = r0; if (CB > 1) rs.bnd[seg * CB + 1] = r1; }
+    }
+    __syncthreads();
+    BSSM_STAMP(st, dbg, MODE, 2, stamper);
+    long long lit = 0;
+    const int nent = nb * CB;
+    if (t < 64) {
+        // boundary walk.  One wave; lane j owns the j-th block of the boundary chunks with its record in registers; the
+        // exact state travels in scalar registers (walk_chain_regs), what the chain cannot take is stepped lane to lane.
+        const int lane = t;
+        const bool fits = (nb <= MAXBND) && (nent <= 64);
+        const bool have = fits && lane < nent;
+        const int k = have ? lane / CB : 0;
+        int bidx = -1;
+        Pure ex; ex.d0 = 0; ex.d1 = 0;
+        Rec pr = rec_identity(0);
+        int nside = 0;
+        bool slow = false;
+        if (have) {
+            bidx = sm.bnd_lane[k] * CB + (lane % CB);
+            if (bidx >= upto) bidx = -1;
+            if (lane % CB == 0) ex = sm.bnd_excl[k];
+        }
+        if (bidx >= 0) {
+            pr = rs.bnd[lane].prefix; nside = rs.bnd[lane].nside;
+            slow = (nside > 1) || (rs.bnd[lane].tail_from < NT);
+            if (nside == 1 && !slow && !(bidx == upto - 1 && lane < 63)) {       // (the last block's entry is already in slot 63)
+                const uint4* sp = reinterpret_cast<const uint4*>(&side[bidx].e[0]);
+                uint4* dp = reinterpret_cast<uint4*>(&rs.sideC[lane]);
+#pragma unroll
+                for (int q = 0; q < (int)(sizeof(SideEntry) / 16); q++) dp[q] = sp[q];
+            }
+        }
+        if (!fits) { if (lane == 0) sm.fail = 1; }
+        else {
+            uint64_t s = 0, my_out = 0, my_s0 = 0;
+            const bool special = (bidx >= 0) && (slow || nside == 1);
+            const StepFn fn = stepfn_build(ex, pr);          // "PURE run + this block's record" folded into constants
+            const WalkFn wfn = walkfn_from(fn, lane < nent && bidx >= 0 && !special);
+            BSSM_STAMP(st, dbg, MODE, 3, stamper && wfn.sh >= 0);
+            const int j0 = walk_chain_regs(wfn, nent, s, my_s0, my_out);
+            BSSM_STAMP(st, dbg, MODE, 4, stamper && s != 1);
+            for (int j = j0; j < nent; j++) {
+                bool ok;
+                uint64_t o = stepfn_apply(fn, s, ok);
+                const uint64_t e = pure_step(ex, s);         // (only lane j's copy is used)
+                if (bidx < 0) { o = e; ok = true; }
+                if (lane == j && (special || !ok)) {             // rare: side entry / tails / window miss
+                    bool done = false;
+                    if (!slow && ok && nside == 1) {
+                        const SideEntry& se = rs.sideC[(bidx == upto - 1) ? 63 : lane];
+                        bool ok2 = true;
+                        uint64_t o2 = rec_step(se.leaf, o, ok2);
+                        if (!ok2) {                          // HARD leaf: its 8 terms literally (kept in the entry)
+                            double c = b2d(o);
+#pragma unroll
+                            for (int q = 0; q < EL; q++) c = c + se.terms[q];
+                            o2 = d2b(c);
+                        }
+                        done = true;
+                        if (se.pad) {
+                            const int64_t diff = (int64_t)(o2 - se.post_base);
+                            if (diff < (int64_t)se.lo || diff > (int64_t)se.hi) done = false;
+                            else { Pure pp; pp.d0 = se.d0; pp.d1 = se.d1; o2 = pure_step(pp, o2); }
+                        }
+                        if (done) o = o2;
+                    }
+                    if (!done) o = block_out_exact<MODE>(rs.bnd[lane], side, w, nw, total, bidx, e, lit);   // the general (slower) routine
+                }
+                if (lane == j) my_out = o;
+                s = readlane_u64(o, j);
+            }
+            BSSM_STAMP(st, dbg, MODE, 5, stamper && s != 1);
+            if (lane == 0) sm.seg_start[0] = 0;
+            if (have) {
+                if (lane % CB == CB - 1) sm.seg_start[k + 1] = my_out;
+                if (bidx == upto - 1) rs.result = my_out;
+            }
+        }
+    }
+    __syncthreads();
+    BSSM_STAMP(st, dbg, MODE, 6, stamper);
+    if (!sm.fail && c0 < c1 && !isb) {
+        const uint64_t ent = pure_step(exc, sm.seg_start[seg]);
+        const long long diff = (long long)(ent - cbase);
+        if (diff < wlo || diff > whi) sm.fail = 1;
+        else if (c1 == upto) {                               // this thread holds the last block of the range
+            uint64_t s = ent;
+            bool ok = true;
+            s = rec_step(r0.prefix, s, ok);
+            if (c0 + 1 < c1) s = rec_step(r1.prefix, s, ok);
+            if (!ok) sm.fail = 1; else rs.result = s;
+        }
+    }
+    __syncthreads();
+    if (sm.fail) {
+        // the records did not cover the exact states: one lane walks every block (each step is still exact)
+        if (t == 0) {
+            uint64_t s = 0;
+            for (int b = 0; b < upto; b++) { const BlockRec r = brec[b]; s = block_out_exact<MODE>(r, side, w, nw, total, b, s, lit); }
+            rs.result = s;
+            if (count_stats) atomicAdd((unsigned long long*)&st->stat_serial_walks, 1ull);
+        }
+        __syncthreads();
+    }
+    if (lit && count_stats) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
+    BSSM_STAMP(st, dbg, MODE, 7, stamper);
+#ifdef BSSM_DEV_STAMPS
+    if ((dbg == 99 || dbg == 98) && stamper) { st->stamps[MODE][8] = nb; st->stamps[MODE][9] = upto; }
+#endif
+    return rs.result;
+}
+
+// prev_brec != nullptr (MODE_P only): this pass's workgroups resolve the MODE_W pass before them themselves -- exact
+// total = sum(w), their own approximate prefix of w / total -- instead of a k_resolve<W> launch in between.
+// (INRES is a template parameter so that the plain variants keep their register budget: the resolve costs ~40 VGPRs)
+template <int MODE, bool FROM_LW, bool INRES = false>
+__global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long long nw, const double* __restrict__ ain,
+                                              int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
+                                              FromLw f, const BlockRec* __restrict__ prev_brec, const SideList* __restrict__ prev_side,
+                                              double* __restrict__ ain_p_out)
+{
+    __shared__ SegSmem sm;
+    __shared__ uint64_t tin[NT];
+    __shared__ double es[1];
+    PassIn pin; pin.given = false; pin.total = 1.0; pin.a_in = 0.0;
+    if constexpr (INRES) {
+        static_assert(!INRES || (MODE == MODE_P && !FROM_LW), "only the cumsum pass resolves the pass before it");
+        __shared__ ResolveSmem rs;
+        {
+            const double ain_w = ain[blockIdx.x];
+            if (st->dead || st->flags || !st->do_resample) return;
+            const uint64_t tb = resolve_in_block<MODE_W>(sm, rs, prev_brec, prev_side, (int)gridDim.x, (int)gridDim.x, w, nw, 1.0, st, blockIdx.x == 0);
+            const double tot = b2d(tb);
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                st->total_bits = tb;
+                if (tot == 0.0) atomicOr(&st->flags, FLAG_ZERO_SUM);       // src/resampling.cpp:8,22,49
+                if (!isfinite(tot)) atomicOr(&st->flags, FLAG_NONFINITE);
+            }
+            if (tot == 0.0 || !isfinite(tot)) return;
+            pin.given = true; pin.total = tot; pin.a_in = ain_w / tot;
+            if (threadIdx.x == 0) ain_p_out[blockIdx.x] = pin.a_in;
+        }
+    }
+    local_block<MODE, FROM_LW, MAXB>(sm, tin, es, (int)blockIdx.x, (int)gridDim.x, w, nw, ain, lim, brec, side, st, f, pin);
 }
 
 constexpr int NTR = 1024;        // threads of the single resolve workgroup (16 waves)
@@ -1550,7 +1758,8 @@ constexpr int CAPX = 3072;       // outputs a block can stage in LDS for the coa
 
 template <int KIND, bool LIT = false>
 __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
-                                            const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [nstage][CAPX] or nullptr */, const int nstage = 0)
+                                            const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [nstage][CAPX] or nullptr */, const int nstage = 0,
+                                            const bool has_cin = false, const uint64_t cin_val = 0)
 {
     const int t = threadIdx.x;
     const long long b0 = (long long)bidx * EB;
@@ -1581,7 +1790,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         }
     }
     const double a_in_p = a.ain_p[bidx];
-    const uint64_t cinb = a.cin[bidx];
+    const uint64_t cinb = has_cin ? cin_val : a.cin[bidx];
     if (s_dead || !s_do || s_flags) return;
     if (t == 0) sm.big = 0;
     // the uniform(s) of this resample call (systematic: one draw; computed here, under the load latency)
@@ -1737,15 +1946,29 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
 }
 
 
-template <int KIND>
-__global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st)
+// prev_brec != nullptr: every workgroup resolves the MODE_P pass for itself (its own exact incoming state) instead of a
+// k_resolve<P> launch in between.
+template <int KIND, bool INRES = false>
+__global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st, const BlockRec* __restrict__ prev_brec,
+                                              const SideList* __restrict__ prev_side)
 {
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT];
     __shared__ int Tl[EB];
     __shared__ int Tbegin;
     extern __shared__ __attribute__((aligned(16))) double lx[];      // [a.nstage][CAPX], sized by the launch
-    apply_block<KIND>(sm, tin, Tl, Tbegin, (int)blockIdx.x, (int)gridDim.x, a, st, a.nstage ? lx : nullptr, a.nstage);
+    bool has_cin = false;
+    uint64_t cin_val = 0;
+    if constexpr (INRES) {
+        // (the resolve's scratch lives in the staging area, which is not in use yet: the launch sizes the dynamic LDS for both)
+        ResolveSmem& rs = *reinterpret_cast<ResolveSmem*>(lx);
+        if (st->dead || !st->do_resample || st->flags) return;
+        cin_val = resolve_in_block<MODE_P>(sm, rs, prev_brec, prev_side, (int)gridDim.x, (int)blockIdx.x, a.w, a.nw, b2d(st->total_bits), st,
+                                           blockIdx.x == gridDim.x - 1);
+        has_cin = true;
+        __syncthreads();                                             // the staging area is free again
+    }
+    apply_block<KIND>(sm, tin, Tl, Tbegin, (int)blockIdx.x, (int)gridDim.x, a, st, a.nstage ? lx : nullptr, a.nstage, has_cin, cin_val);
 }
 
 // multinomial: inverse CDF on the exact cum_sum (distributional parity only)
