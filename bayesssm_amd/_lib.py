@@ -55,6 +55,7 @@ class PmmhConfig(C.Structure):
         ("init_theta", C.c_void_p), ("proposal_cov", C.c_void_p), ("transform", C.c_void_p),
         ("prior_kind", C.c_void_p), ("prior_a", C.c_void_p), ("prior_b", C.c_void_p),
         ("seed", C.c_ulonglong), ("chain_index", C.c_int), ("return_latent_state_est", C.c_int),
+        ("z_prop", C.c_void_p), ("u_accept", C.c_void_p),
     ]
 
 
@@ -108,6 +109,7 @@ def load():
     lib.bssm_dump_move_draws.argtypes = [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
     lib.bssm_pmmh_chain.argtypes = [C.c_void_p, C.POINTER(PmmhConfig), C.POINTER(PmmhResult)]
     lib.bssm_pmmh_chains_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bssm_pmmh_chain_draws.argtypes = [C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.bssm_pf_run_batch.argtypes = [C.c_void_p, C.POINTER(PfConfig), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(PfBatchResult)]
     _lib = lib
@@ -120,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "bssm_resample_multinomial", "bssm_resample_device", "bssm_resample_device_status", "bssm_resample_ex",
     "bssm_pf_run", "bssm_pf_noise_shape", "bssm_dump_normals", "bssm_dump_uniforms", "bssm_dump_move_draws",
     "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_pmmh_chain",
-    "bssm_pf_run_batch", "bssm_pf_batch_max_particles", "bssm_pmmh_chains_batch",
+    "bssm_pf_run_batch", "bssm_pf_batch_max_particles", "bssm_pmmh_chains_batch", "bssm_pmmh_chain_draws",
 ]
 
 

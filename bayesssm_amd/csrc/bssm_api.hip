@@ -850,6 +850,53 @@ static double tr_fwd(int tr, double x) { return tr == BSSM_TR_LOG ? log(x) : tr 
 static double tr_back(int tr, double z) { return tr == BSSM_TR_LOG ? exp(z) : tr == BSSM_TR_LOGIT ? 1 / (1 + exp(-z)) : z; }        // R/utils.R:122-132
 static double tr_logjac(int tr, double x) { return tr == BSSM_TR_LOG ? log(x) : tr == BSSM_TR_LOGIT ? log(1 / (x * (1 - x))) : 0.0; }  // R/utils.R:142-152
 
+// fac = V diag(sqrt(max(ev, 0))) of the symmetric matrix S (row-major p x p)
+static int eigen_factor(int p, const double* S, double* fac)
+{
+    std::vector<double> A((size_t)p * p), V((size_t)p * p);
+    for (int a = 0; a < p; a++) for (int b = 0; b < p; b++) { A[a * p + b] = 0.5 * (S[a * p + b] + S[b * p + a]); V[a * p + b] = (a == b); }
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0.0;
+        for (int a = 0; a < p; a++) for (int b = a + 1; b < p; b++) off += A[a * p + b] * A[a * p + b];
+        if (off == 0.0) break;
+        for (int a = 0; a < p - 1; a++) for (int b = a + 1; b < p; b++) {
+            const double apq = A[a * p + b];
+            if (apq == 0.0) continue;
+            const double th = (A[b * p + b] - A[a * p + a]) / (2.0 * apq);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < p; k++) {
+                const double aka = A[k * p + a], akb = A[k * p + b];
+                A[k * p + a] = c * aka - sn * akb; A[k * p + b] = sn * aka + c * akb;
+                const double vka = V[k * p + a], vkb = V[k * p + b];
+                V[k * p + a] = c * vka - sn * vkb; V[k * p + b] = sn * vka + c * vkb;
+            }
+            for (int k = 0; k < p; k++) {
+                const double aak = A[a * p + k], abk = A[b * p + k];
+                A[a * p + k] = c * aak - sn * abk; A[b * p + k] = sn * aak + c * abk;
+            }
+        }
+    }
+    std::vector<int> order(p);
+    for (int k = 0; k < p; k++) order[k] = k;
+    for (int i = 1; i < p; i++) {
+        const int o = order[i]; int j = i - 1;
+        while (j >= 0 && A[order[j] * p + order[j]] < A[o * p + o]) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = o;
+    }
+    const double ev0 = A[order[0] * p + order[0]];
+    for (int k = 0; k < p; k++) {
+        const int o = order[k];
+        const double ev = A[o * p + o];
+        if (!(ev >= -1e-6 * fabs(ev0))) ARGFAIL("'Sigma' is not positive definite");
+        int big = 0;
+        for (int a = 1; a < p; a++) if (fabs(V[a * p + o]) > fabs(V[big * p + o])) big = a;
+        const double sg = (V[big * p + o] < 0) ? -1.0 : 1.0;
+        for (int a = 0; a < p; a++) fac[a * p + k] = (sg * V[a * p + o]) * sqrt(ev > 0 ? ev : 0.0);
+    }
+    return BSSM_OK;
+}
+
 // One chain's Metropolis-Hastings state: everything of R/pmmh.R:345-505 except the filter run itself, so that the
 // same code drives one chain over bssm_pf_run and many chains in lock-step over bssm_pf_run_batch.
 struct ChainState {
@@ -870,22 +917,19 @@ struct ChainState {
             ARGFAIL("bssm_pmmh_chain: NULL configuration array");
         if (!res->theta_chain) ARGFAIL("bssm_pmmh_chain: theta_chain buffer missing");
         // proposal covariance on the transformed scale: J Sigma J, J = diag(dz/dtheta at init_theta)   R/pmmh.R:378-389
-        std::vector<double> scale(p), cov(p * p);
+        std::vector<double> scale(p), cov((size_t)p * p);
         L.assign((size_t)p * p, 0.0);
         for (int j = 0; j < p; j++) {
             const double th = cfg->init_theta[j];
             scale[j] = cfg->transform[j] == BSSM_TR_LOG ? 1 / th : cfg->transform[j] == BSSM_TR_LOGIT ? 1 / (th * (1 - th)) : 1.0;
         }
         for (int a = 0; a < p; a++) for (int b = 0; b < p; b++) cov[a * p + b] = scale[a] * cfg->proposal_cov[a * p + b] * scale[b];
-        // mvrnorm(1, mu, Sigma): Cholesky factor here (MASS uses an eigen-decomposition; same law)
-        for (int a = 0; a < p; a++) {
-            for (int b = 0; b <= a; b++) {
-                double s = cov[a * p + b];
-                for (int k = 0; k < b; k++) s -= L[a * p + k] * L[b * p + k];
-                if (a == b) { if (!(s > 0)) ARGFAIL("'Sigma' is not positive definite"); L[a * p + a] = sqrt(s); }
-                else L[a * p + b] = s / L[b * p + b];
-            }
-        }
+        // MASS::mvrnorm(1, mu, Sigma) (R/pmmh.R:425-428):  mu + V diag(sqrt(pmax(ev, 0))) z  with eigen(Sigma, symmetric = TRUE),
+        // "'Sigma' is not positive definite" only when an eigenvalue is below -1e-6 |ev[1]| -- a positive SEMI-definite pilot
+        // covariance (a parameter that never moved in the pilot's second half) is accepted, the chain just does not move in
+        // the null directions.  Eigen-solver: cyclic Jacobi (p <= 16), eigenvalues decreasing, each eigenvector's largest
+        // component positive (LAPACK's sign choice is build-dependent; same law either way).
+        if (int rc = eigen_factor(p, cov.data(), L.data())) return rc;
         ckey = make_key(cfg->seed, 0x50000000ull + (unsigned long long)cfg->chain_index);
         cur.assign(cfg->init_theta, cfg->init_theta + p); prop.assign(p, 0.0); lp_prop.assign(p, 0.0);
         dim = (cfg->pf.model == BSSM_MODEL_SIR) ? 2 : 1;
@@ -910,8 +954,11 @@ struct ChainState {
     bool propose(int i)
     {
         std::vector<double> z(p), ztr(p);
-        for (int j = 0; j < p; j++) { ztr[j] = tr_fwd(cfg->transform[j], cur[j]); z[j] = host_normal(ckey, (uint32_t)i, (uint32_t)j); }
-        for (int a = 0; a < p; a++) { double s = ztr[a]; for (int k = 0; k <= a; k++) s += L[a * p + k] * z[k]; prop[a] = tr_back(cfg->transform[a], s); }
+        for (int j = 0; j < p; j++) {
+            ztr[j] = tr_fwd(cfg->transform[j], cur[j]);
+            z[j] = cfg->z_prop ? cfg->z_prop[(size_t)i * p + j] : host_normal(ckey, (uint32_t)i, (uint32_t)j);       // rnorm(p) of mvrnorm
+        }
+        for (int a = 0; a < p; a++) { double s = 0.0; for (int k = 0; k < p; k++) s += L[a * p + k] * z[k]; prop[a] = tr_back(cfg->transform[a], ztr[a] + s); }
         bool finite = true;
         for (int j = 0; j < p; j++) { lp_prop[j] = log_prior(cfg->prior_kind[j], cfg->prior_a[j], cfg->prior_b[j], prop[j]); if (!isfinite(lp_prop[j])) finite = false; }
         if (!finite) store(i);
@@ -920,17 +967,31 @@ struct ChainState {
     // accept / reject with the proposal's log-likelihood (se_prop filled by the caller)   :461-496
     void finish(int i, double prop_ll)
     {
-        double lj_prop = 0, lj_cur = 0, slp_prop = 0, slp_cur = 0;
+        long double lj_prop = 0, lj_cur = 0, slp_prop = 0, slp_cur = 0;                  // R's sum() accumulates in long double
         for (int j = 0; j < p; j++) {
             lj_prop += tr_logjac(cfg->transform[j], prop[j]); lj_cur += tr_logjac(cfg->transform[j], cur[j]);   // :461-469
             slp_prop += lp_prop[j]; slp_cur += log_prior(cfg->prior_kind[j], cfg->prior_a[j], cfg->prior_b[j], cur[j]);
         }
-        double lar = (prop_ll + slp_prop + lj_prop) - (cur_ll + slp_cur + lj_cur);       // :475-486
+        const double num = prop_ll + (double)slp_prop + (double)lj_prop;                 // :475-478
+        const double den = cur_ll + (double)slp_cur + (double)lj_cur;                    // :480-483
+        double lar = num - den;                                                          // :485
         if (isnan(lar)) lar = -INFINITY;                                                 // :488-490
-        if (log(host_uniform(ckey, (uint32_t)i)) < lar) { cur = prop; cur_ll = prop_ll; se_cur = se_prop; accepted++; }   // :492-496
+        const double u = cfg->u_accept ? cfg->u_accept[i] : host_uniform(ckey, (uint32_t)i);
+        if (log(u) < lar) { cur = prop; cur_ll = prop_ll; se_cur = se_prop; accepted++; }   // :492-496
         store(i);
     }
 };
+
+extern "C" int bssm_pmmh_chain_draws(unsigned long long seed, int chain_index, int m, int n_params, double* z_prop_out, double* u_accept_out)
+{
+    if (m < 1 || n_params < 1 || !z_prop_out || !u_accept_out) ARGFAIL("bssm_pmmh_chain_draws: bad argument");
+    const PhiloxKey ckey = make_key(seed, 0x50000000ull + (unsigned long long)chain_index);
+    for (int i = 0; i < m; i++) {
+        for (int j = 0; j < n_params; j++) z_prop_out[(size_t)i * n_params + j] = host_normal(ckey, (uint32_t)i, (uint32_t)j);
+        u_accept_out[i] = host_uniform(ckey, (uint32_t)i);
+    }
+    return BSSM_OK;
+}
 
 extern "C" int bssm_pmmh_chain(bssm_ctx* c, const bssm_pmmh_config* cfg, bssm_pmmh_result* res)
 {

@@ -193,10 +193,20 @@ def gather_chains(local, num_chains, m, p, dist=None):
     return out
 
 
+def chain_draws(seed, chain_index, m, n_params):
+    """The chain-level draws of chain (seed, chain_index): z_prop (m, n_params) -- mvrnorm's rnorm(n_params) per iteration
+    (R/pmmh.R:425) -- and u_accept (m,) -- the acceptance test's runif(1) (:492) -- as the device chain consumes them."""
+    z, u = np.zeros((m, n_params)), np.zeros(m)
+    _lib.check(_lib.load().bssm_pmmh_chain_draws(int(seed), int(chain_index), int(m), int(n_params),
+                                                 z.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p)))
+    return {"z_prop": z, "u_accept": u}
+
+
 def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov, transform, priors, num_particles,
                      seed, chain_index, obs_times=None, resample_algorithm="SISAR", resample_fn="stratified",
-                     return_latent_state_est=False, ctx=None, model_constants=None):
-    """One chain of R/pmmh.R:403-415,422-500 on this process's GPU (bssm_pmmh_chain)."""
+                     return_latent_state_est=False, ctx=None, model_constants=None, draws=None):
+    """One chain of R/pmmh.R:403-415,422-500 on this process's GPU (bssm_pmmh_chain).  `draws` (parity mode):
+    dict(z_prop (m, n_params), u_accept (m,)) of injected chain-level draws."""
     y = np.ascontiguousarray(y, dtype=np.float64)
     T = y.size
     dim = models.dim_of(model)
@@ -214,8 +224,12 @@ def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov
     pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
                        _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, ptr(consts), int(consts.size),
                        ptr(y), ptr(ot), int(seed), 0, None, None, None, 0, 0)
+    zp = np.ascontiguousarray(draws["z_prop"], dtype=np.float64) if draws is not None else None
+    ua = np.ascontiguousarray(draws["u_accept"], dtype=np.float64) if draws is not None else None
+    if draws is not None and (zp.size < m * n_params or ua.size < m):
+        raise ValueError("draws: z_prop must hold m x n_params values, u_accept m")
     cfg = _lib.PmmhConfig(pf, int(m), int(n_params), ptr(init_theta), ptr(cov), ptr(tr), ptr(pk), ptr(pa), ptr(pb),
-                          int(seed), int(chain_index), 1 if return_latent_state_est else 0)
+                          int(seed), int(chain_index), 1 if return_latent_state_est else 0, ptr(zp), ptr(ua))
     theta_chain = np.zeros((m, n_params))
     ll_chain = np.zeros(m)
     se_chain = np.zeros((m, T + 1, dim) if dim > 1 else (m, T + 1)) if return_latent_state_est else None
@@ -259,7 +273,8 @@ def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, prop
                            _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, ptr(consts), int(consts.size),
                            ptr(y), ptr(ot), int(seeds[k]), 0, None, None, None, 0, 0)
         cfgs.append(_lib.PmmhConfig(pf, int(m), int(n_params), ptr(init_theta), ptr(cov), ptr(tr), ptr(pk), ptr(pa),
-                                    ptr(pb), int(seeds[k]), int(chain_indices[k]), 1 if return_latent_state_est else 0))
+                                    ptr(pb), int(seeds[k]), int(chain_indices[k]), 1 if return_latent_state_est else 0,
+                                    None, None))
         theta_chain = np.zeros((m, n_params))
         ll_chain = np.zeros(m)
         dim = models.dim_of(model)
@@ -460,6 +475,7 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
             futs = {it: ex.submit(task, it) for it in items}
             return {it: futs[it].result() for it in items}
 
+    failure = None
     try:
         preps = run_pool(prepare, list(mine))
         results = {}
@@ -484,9 +500,21 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
         for c in mine:
             if preps[c]["pilot"] is not None:
                 results[c]["pilot"] = preps[c]["pilot"]
+    except Exception as e:           # noqa: BLE001 -- re-raised below, after the other ranks have been told
+        failure = e
     finally:
         for cx in ctxs:
             cx.close()
+    if dist is not None and world > 1:
+        # a rank that failed must not leave the others blocked in the gather: exchange an error flag first
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1.0 if failure is not None else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if failure is None and float(flag.item()) > 0:
+            raise RuntimeError("pmmh: a chain failed on another rank")
+    if failure is not None:
+        raise failure
     for c in mine:
         local[c] = results[c]["theta_chain"]
         extras[c] = results[c]

@@ -221,6 +221,11 @@ typedef struct {
     unsigned long long seed;   /* chain seed (R/pmmh.R:346,511)                   */
     int chain_index;
     int return_latent_state_est;
+    /* parity mode: the chain-level draws as INPUTS (host pointers); NULL => the generator keyed by (seed, chain_index).
+     * z_prop[i][0..n_params) = the rnorm(n_params) MASS::mvrnorm takes at iteration i (R/pmmh.R:425), u_accept[i] = the
+     * runif(1) of the acceptance test (:492); row / entry 0 are not used (the loop starts at i = 2 in R). */
+    const double* z_prop;      /* [m][n_params] or NULL */
+    const double* u_accept;    /* [m] or NULL */
 } bssm_pmmh_config;
 
 typedef struct {
@@ -232,6 +237,9 @@ typedef struct {
 } bssm_pmmh_result;
 
 int bssm_pmmh_chain(bssm_ctx* ctx, const bssm_pmmh_config* cfg, bssm_pmmh_result* res);
+/* The chain-level draws the generator gives chain (seed, chain_index): what a CPU run of the same loop consumes
+ * (z_prop_out [m][n_params], u_accept_out [m]; host pointers, no GPU needed). */
+int bssm_pmmh_chain_draws(unsigned long long seed, int chain_index, int m, int n_params, double* z_prop_out, double* u_accept_out);
 
 /* n_chains chains advancing in lock-step over bssm_pf_run_batch: iteration i of every chain is ONE kernel launch (one
  * workgroup per chain).  The chains must share data, filter settings and m, and meet bssm_pf_run_batch's limits

@@ -573,3 +573,160 @@ double orc_mcmc_ess(int m, int k, const double *mat)
     free(mean); free(var); free(rho); free(acf);
     return ((double)k * m) / tau;                                      /* :101 */
 }
+
+/* ------------------------------------------------------------------------- */
+/* PMMH per-chain loop: chain_result, R/pmmh.R:403-415,422-500                */
+/* ------------------------------------------------------------------------- */
+/* Random draws are INPUTS, as everywhere in this file: z_prop[i][0..p) are the p standard normals mvrnorm draws at
+ * iteration i (rnorm(p), MASS::mvrnorm), u_accept[i] is the runif(1) of the acceptance test (:492).  The particle filter
+ * is a callback, so that the same loop can be driven by this file's orc_pf_run or by the filter under test.
+ *
+ * MASS::mvrnorm(1, mu, Sigma) is third-party (MASS, unpinned, not under /root/reference); its published algorithm:
+ *   eS <- eigen(Sigma, symmetric = TRUE); stop("'Sigma' is not positive definite") unless all(ev >= -1e-6 * abs(ev[1]));
+ *   mu + eS$vectors %*% diag(sqrt(pmax(ev, 0))) %*% rnorm(p)
+ * restated here with a cyclic Jacobi eigen-solver (eigenvalues in decreasing order as eigen() returns them; each
+ * eigenvector's sign fixed by "largest component positive" -- LAPACK's sign choice is build-dependent and NOT reproduced:
+ * same law, "parity unpinned" for the proposal stream). */
+enum { ORC_PRIOR_NORMAL = 0, ORC_PRIOR_EXP = 1, ORC_PRIOR_UNIFORM = 2, ORC_PRIOR_FLAT = 3, ORC_PRIOR_HALFNORMAL = 4 };
+#define ORC_PMAX 16
+#define ORC_ERR_SIGMA 5      /* "'Sigma' is not positive definite" */
+
+typedef double (*orc_pf_fn)(const double *theta, int iter, double *state_est, void *user);
+
+typedef struct {
+    int p, m;
+    const double *init_theta;       /* p: pilot_theta_mean (R/pmmh.R:373)                       */
+    const double *proposal_cov;     /* p x p on the original scale: pilot_theta_cov (:374)      */
+    const int *transform;           /* ORC_TR_* per parameter                                   */
+    const int *prior_kind;          /* ORC_PRIOR_* per parameter                                */
+    const double *prior_a, *prior_b;
+    const double *z_prop;           /* [m][p]; row 0 unused                                     */
+    const double *u_accept;         /* [m];   entry 0 unused                                    */
+    orc_pf_fn pf; void *user;
+    int se_len;                     /* doubles per state estimate ((T+1) d), 0: none            */
+    double *theta_chain;            /* m x p row-major                                          */
+    double *loglike_chain;          /* m                                                        */
+    double *state_est_chain;        /* m x se_len, or NULL                                      */
+    int *accepted; int *pf_calls;
+} orc_pmmh_args;
+
+/* the R closures of log_priors for the built-in kinds: dnorm / dexp / dunif / extraDistr::dhnorm (log = TRUE) */
+static double orc_log_prior(int kind, double a, double b, double x)
+{
+    switch (kind) {
+        case ORC_PRIOR_NORMAL: { double z = (x - a) / b; return -(ORC_LN_SQRT_2PI + 0.5 * z * z + log(b)); }
+        case ORC_PRIOR_EXP: return (x < 0) ? -INFINITY : (log(a) - a * x);
+        case ORC_PRIOR_UNIFORM: return (x >= a && x <= b) ? -log(b - a) : -INFINITY;
+        case ORC_PRIOR_HALFNORMAL: { if (x < 0) return -INFINITY; double z = x / a; return log(2.0) - (ORC_LN_SQRT_2PI + 0.5 * z * z + log(a)); }
+        default: return 0.0;
+    }
+}
+
+/* symmetric eigen-decomposition, cyclic Jacobi; ev decreasing, vec[a*p+k] = component a of eigenvector k */
+static void orc_eigen_sym(int p, const double *S, double *ev, double *vec)
+{
+    double A[ORC_PMAX * ORC_PMAX], V[ORC_PMAX * ORC_PMAX];
+    for (int a = 0; a < p; a++) for (int b = 0; b < p; b++) { A[a * p + b] = 0.5 * (S[a * p + b] + S[b * p + a]); V[a * p + b] = (a == b); }
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0.0;
+        for (int a = 0; a < p; a++) for (int b = a + 1; b < p; b++) off += A[a * p + b] * A[a * p + b];
+        if (off == 0.0) break;
+        for (int a = 0; a < p - 1; a++) for (int b = a + 1; b < p; b++) {
+            const double apq = A[a * p + b];
+            if (apq == 0.0) continue;
+            const double th = (A[b * p + b] - A[a * p + a]) / (2.0 * apq);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < p; k++) {      /* columns a, b of A and V */
+                const double aka = A[k * p + a], akb = A[k * p + b];
+                A[k * p + a] = c * aka - s * akb; A[k * p + b] = s * aka + c * akb;
+                const double vka = V[k * p + a], vkb = V[k * p + b];
+                V[k * p + a] = c * vka - s * vkb; V[k * p + b] = s * vka + c * vkb;
+            }
+            for (int k = 0; k < p; k++) {      /* rows a, b of A */
+                const double aak = A[a * p + k], abk = A[b * p + k];
+                A[a * p + k] = c * aak - s * abk; A[b * p + k] = s * aak + c * abk;
+            }
+        }
+    }
+    int order[ORC_PMAX];
+    for (int k = 0; k < p; k++) order[k] = k;
+    for (int i = 1; i < p; i++) {              /* insertion sort, decreasing, stable */
+        int o = order[i], j = i - 1;
+        while (j >= 0 && A[order[j] * p + order[j]] < A[o * p + o]) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = o;
+    }
+    for (int k = 0; k < p; k++) {
+        const int o = order[k];
+        ev[k] = A[o * p + o];
+        int big = 0;
+        for (int a = 1; a < p; a++) if (fabs(V[a * p + o]) > fabs(V[big * p + o])) big = a;
+        const double sg = (V[big * p + o] < 0) ? -1.0 : 1.0;
+        for (int a = 0; a < p; a++) vec[a * p + k] = sg * V[a * p + o];
+    }
+}
+
+int orc_pmmh_chain(orc_pmmh_args *a)
+{
+    const int p = a->p, m = a->m;
+    if (p < 1 || p > ORC_PMAX || m < 1) return ORC_ERR_ARG;
+    double cov[ORC_PMAX * ORC_PMAX], ev[ORC_PMAX], vec[ORC_PMAX * ORC_PMAX], fac[ORC_PMAX * ORC_PMAX];
+    /* proposal_cov_trans = diag(scale) %*% proposal_cov %*% diag(scale), scale = dz/dtheta at init_theta   (:378-389) */
+    for (int i = 0; i < p; i++) for (int j = 0; j < p; j++) {
+        const double ti = a->init_theta[i], tj = a->init_theta[j];
+        const double si = a->transform[i] == ORC_TR_LOG ? 1 / ti : a->transform[i] == ORC_TR_LOGIT ? 1 / (ti * (1 - ti)) : 1.0;
+        const double sj = a->transform[j] == ORC_TR_LOG ? 1 / tj : a->transform[j] == ORC_TR_LOGIT ? 1 / (tj * (1 - tj)) : 1.0;
+        cov[i * p + j] = si * a->proposal_cov[i * p + j] * sj;
+    }
+    orc_eigen_sym(p, cov, ev, vec);
+    for (int k = 0; k < p; k++) if (!(ev[k] >= -1e-6 * fabs(ev[0]))) return ORC_ERR_SIGMA;
+    for (int i = 0; i < p; i++) for (int k = 0; k < p; k++) fac[i * p + k] = vec[i * p + k] * sqrt(ev[k] > 0 ? ev[k] : 0.0);
+    double cur[ORC_PMAX], prop[ORC_PMAX], ztr[ORC_PMAX], lp_prop[ORC_PMAX];
+    double *se_cur = a->se_len ? (double *)calloc((size_t)a->se_len, sizeof(double)) : NULL;
+    double *se_prop = a->se_len ? (double *)calloc((size_t)a->se_len, sizeof(double)) : NULL;
+    for (int j = 0; j < p; j++) cur[j] = a->init_theta[j];
+    int accepted = 0, calls = 0;
+    double cur_ll = a->pf(cur, 0, se_cur, a->user);                                          /* :403-417 */
+    calls++;
+#define ORC_STORE(i) do { for (int j_ = 0; j_ < p; j_++) a->theta_chain[(size_t)(i) * p + j_] = cur[j_];                    \
+        if (a->loglike_chain) a->loglike_chain[i] = cur_ll;                                                                   \
+        if (a->state_est_chain && a->se_len) memcpy(a->state_est_chain + (size_t)(i) * a->se_len, se_cur, sizeof(double) * (size_t)a->se_len); } while (0)
+    ORC_STORE(0);
+    for (int i = 1; i < m; i++) {                                                             /* for (i in 2:m)  :422 */
+        orc_transform_params(p, cur, a->transform, ztr);                                      /* :424 */
+        double ptr[ORC_PMAX];
+        for (int r = 0; r < p; r++) {                                                         /* mvrnorm :425-428 */
+            double s = 0.0;
+            for (int k = 0; k < p; k++) s += fac[r * p + k] * a->z_prop[(size_t)i * p + k];
+            ptr[r] = ztr[r] + s;
+        }
+        orc_back_transform_params(p, ptr, a->transform, prop);                                /* :429-432 */
+        int finite = 1;
+        for (int j = 0; j < p; j++) { lp_prop[j] = orc_log_prior(a->prior_kind[j], a->prior_a[j], a->prior_b[j], prop[j]); if (!isfinite(lp_prop[j])) finite = 0; }
+        if (!finite) { ORC_STORE(i); continue; }                                              /* :435-442 */
+        const double prop_ll = a->pf(prop, i, se_prop, a->user);                             /* :445-458 */
+        calls++;
+        const double lj_prop = orc_log_jacobian(p, prop, a->transform), lj_cur = orc_log_jacobian(p, cur, a->transform);   /* :461-469 */
+        long double sp = 0.0L, sc = 0.0L;                                                     /* sum() */
+        for (int j = 0; j < p; j++) { sp += lp_prop[j]; sc += orc_log_prior(a->prior_kind[j], a->prior_a[j], a->prior_b[j], cur[j]); }
+        const double num = prop_ll + (double)sp + lj_prop;                                    /* :475-478 */
+        const double den = cur_ll + (double)sc + lj_cur;                                      /* :480-483 */
+        double lar = num - den;                                                               /* :485 */
+        if (isnan(lar)) lar = -INFINITY;                                                      /* :488-490 */
+        if (log(a->u_accept[i]) < lar) {                                                      /* :492-496 */
+            for (int j = 0; j < p; j++) cur[j] = prop[j];
+            cur_ll = prop_ll;
+            if (a->se_len) memcpy(se_cur, se_prop, sizeof(double) * (size_t)a->se_len);
+            accepted++;
+        }
+        ORC_STORE(i);                                                                         /* :498-499 */
+    }
+#undef ORC_STORE
+    if (a->accepted) *a->accepted = accepted;
+    if (a->pf_calls) *a->pf_calls = calls;
+    free(se_cur); free(se_prop);
+    return ORC_OK;
+}
+
+/* eigen-decomposition exposed for its own known-answer tests */
+void orc_eigen_sym_test(int p, const double *S, double *ev, double *vec) { orc_eigen_sym(p, S, ev, vec); }

@@ -233,3 +233,63 @@ def kalman_loglik(y, phi, sigma_x, sigma_y, m0=0.0, p0=1.0):
         k = p / s
         m, p = m + k * (yt - m), (1 - k) * p
     return ll
+
+
+PRIOR = {"normal": 0, "exponential": 1, "uniform": 2, "flat": 3, "halfnormal": 4}
+_PF_CB = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_void_p)
+
+
+class _PmmhArgs(C.Structure):
+    _fields_ = [("p", C.c_int), ("m", C.c_int), ("init_theta", C.c_void_p), ("proposal_cov", C.c_void_p),
+                ("transform", C.c_void_p), ("prior_kind", C.c_void_p), ("prior_a", C.c_void_p), ("prior_b", C.c_void_p),
+                ("z_prop", C.c_void_p), ("u_accept", C.c_void_p), ("pf", _PF_CB), ("user", C.c_void_p),
+                ("se_len", C.c_int), ("theta_chain", C.c_void_p), ("loglike_chain", C.c_void_p),
+                ("state_est_chain", C.c_void_p), ("accepted", C.c_void_p), ("pf_calls", C.c_void_p)]
+
+
+def pmmh_chain(pf, m, init_theta, proposal_cov, transform, priors, z_prop, u_accept, se_len=0):
+    """Restatement of chain_result's loop (R/pmmh.R:403-415,422-500) with injected draws.
+    pf(theta ndarray, iter) -> loglike  or  (loglike, state_est ndarray of se_len);
+    priors: list of (kind, a, b); z_prop (m, p) standard normals, u_accept (m,) uniforms (row / entry 0 unused)."""
+    init_theta = _d(init_theta)
+    p = init_theta.size
+    cov = _d(proposal_cov).reshape(p, p)
+    tr = np.ascontiguousarray([TRANSFORM[t] for t in transform], dtype=np.int32)
+    pk = np.ascontiguousarray([PRIOR[k] for k, _, _ in priors], dtype=np.int32)
+    pa, pb = _d([a for _, a, _ in priors]), _d([b for _, _, b in priors])
+    z, u = _d(z_prop).reshape(m, p), _d(u_accept).reshape(m)
+    theta_chain = np.zeros((m, p))
+    ll_chain = np.zeros(m)
+    se_chain = np.zeros((m, se_len)) if se_len else None
+    acc, calls = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+
+    def cb(theta_ptr, it, se_ptr, _user):
+        th = np.array([theta_ptr[j] for j in range(p)])
+        r = pf(th, int(it))
+        if isinstance(r, tuple):
+            ll, se = r
+            if se_len:
+                se = np.asarray(se, dtype=np.float64).reshape(-1)
+                for k in range(se_len):
+                    se_ptr[k] = se[k]
+            return float(ll)
+        return float(r)
+
+    cbf = _PF_CB(cb)
+    a = _PmmhArgs(p, int(m), _p(init_theta), _p(cov), _p(tr), _p(pk), _p(pa), _p(pb), _p(z), _p(u), cbf, None, int(se_len),
+                  _p(theta_chain), _p(ll_chain), _p(se_chain), _p(acc), _p(calls))
+    st = lib().orc_pmmh_chain(C.byref(a))
+    if st == 5:
+        raise ValueError("'Sigma' is not positive definite")
+    if st:
+        raise ValueError("oracle error %d" % st)
+    return {"theta_chain": theta_chain, "loglike_chain": ll_chain, "state_est_chain": se_chain,
+            "accepted": int(acc[0]), "pf_calls": int(calls[0])}
+
+
+def eigen_sym(S):
+    S = _d(S)
+    p = S.shape[0]
+    ev, vec = np.zeros(p), np.zeros((p, p))
+    lib().orc_eigen_sym_test(C.c_int(p), _p(S), _p(ev), _p(vec))
+    return ev, vec
