@@ -15,7 +15,7 @@ OK, ERR_NEGATIVE, ERR_ZERO_SUM, ERR_LENGTH, ERR_ARG, ERR_HIP, ERR_CAPACITY = ran
 MODEL = {"lg": 0, "ar1sin": 1, "sir": 2}
 ALGORITHM = {"BPF": 0, "APF": 1, "RMPF": 2}
 RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
-RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2}
+RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2, "multinomial_r": 3}
 TRANSFORM = {"identity": 0, "log": 1, "logit": 2}
 PRIOR = {"normal": 0, "exponential": 1, "uniform": 2, "flat": 3, "halfnormal": 4}
 

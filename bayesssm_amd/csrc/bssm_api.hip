@@ -280,6 +280,20 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     f.gmax = r.d_lw ? c->gmax_cur : nullptr;
     f.ain_out = c->ain_w; f.plan = r.plan; f.N = r.nw; f.obs_i = r.obs_i; f.resample_algorithm = r.resample_algorithm;
     f.threshold = r.threshold; f.ess_out = r.d_ess; f.llh_out = r.d_llh; f.resampled_out = r.d_resampled;
+    if (r.kind == BSSM_MULTINOMIAL_R) {
+        // parity mode: Rcpp::sample's own algorithm on the injected unif_rand() stream; no exact scan involved
+        if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr);
+        void *dq, *da, *dh, *danc = r.d_anc;
+        if (pool_get(c, "mr_q", (size_t)r.nw * 8, &dq) || pool_get(c, "mr_a", (size_t)r.nw * 4, &da) || pool_get(c, "mr_hl", (size_t)r.nw * 4, &dh)) return;
+        long long astride = r.anc_stride;
+        if (!danc) { if (pool_get(c, "mr_anc", (size_t)r.n * 4, &danc)) return; astride = 0; }
+        LAUNCH(c, "k_multinomial_r", k_multinomial_r, 1, NTM, 0, r.d_w, r.n, r.d_u, r.u_stride, (int*)danc, astride, (double*)dq, (int*)da, (int*)dh, c->st);
+        if (r.xdst || r.auxdst) {
+            const int Bo = (int)(((long long)r.n + EB - 1) / EB);
+            LAUNCH(c, "k_gather_anc", k_gather_anc, Bo, NT, 0, (const int*)danc, astride, r.n, r.xsrc, r.xdst, r.dim, r.xstride, r.auxsrc, r.auxdst, r.se_part, c->st);
+        }
+        return;
+    }
     // B <= 2 NT: the consuming kernels resolve the pass before them in every workgroup (resolve_in_block); larger grids
     // keep the single-workgroup k_resolve launches (a thread would have to hold more than two block records)
     const bool inres = g_inkernel_resolve && B <= 2 * NT;
@@ -342,7 +356,7 @@ extern "C" int bssm_resample_device(bssm_ctx* c, int kind, int n, const double* 
 {
     if (!c) ARGFAIL("ctx is NULL");
     if (n <= 0 || nw <= 0) ARGFAIL("bssm_resample_device: n and nw must be positive");
-    if (kind < 0 || kind > 2) ARGFAIL("bssm_resample_device: unknown resampler kind");
+    if (kind < 0 || kind > 3) ARGFAIL("bssm_resample_device: unknown resampler kind");
     if ((long long)nw > c->cap || (long long)n > c->cap) { g_err = "bssm_resample_device: size exceeds context capacity"; return BSSM_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(c->device));
     const double* du = d_U;
@@ -372,7 +386,8 @@ extern "C" int bssm_resample_ex(bssm_ctx* c, int kind, int n, const double* w, i
 {
     if (!c) ARGFAIL("ctx is NULL");
     if (!w || !idx_out || !U) ARGFAIL("bssm_resample: NULL pointer argument");
-    if (kind < 0 || kind > 2) ARGFAIL("bssm_resample: unknown resampler kind");
+    if (kind < 0 || kind > 3) ARGFAIL("bssm_resample: unknown resampler kind");
+    if (kind == BSSM_MULTINOMIAL_R && n != nw) ARGFAIL("probs.size() != n!");      // Rcpp::sample's own check
     if (n <= 0 || nw <= 0) ARGFAIL("bssm_resample: n and nw must be positive");
     if ((long long)nw > c->cap || (long long)n > c->cap) { g_err = "bssm_resample: size exceeds context capacity"; return BSSM_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(c->device));
@@ -519,7 +534,8 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     if (rmpf && !(cfg->move_sd > 0)) ARGFAIL("bssm_pf_run: RMPF needs move_sd > 0");
     if (rmpf && ((cfg->z_move == nullptr) != (cfg->u_move == nullptr))) ARGFAIL("bssm_pf_run: z_move and u_move must be given together");
     if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run: unknown resample_algorithm");
-    if (cfg->resample_fn < 0 || cfg->resample_fn > 2) ARGFAIL("bssm_pf_run: unknown resample_fn");
+    if (cfg->resample_fn < 0 || cfg->resample_fn > 3) ARGFAIL("bssm_pf_run: unknown resample_fn");
+    if (cfg->resample_fn == BSSM_MULTINOMIAL_R && !cfg->u_res) ARGFAIL("bssm_pf_run: BSSM_MULTINOMIAL_R replays R's unif_rand() stream: u_res is required");
     if (!cfg->theta || cfg->n_theta < 3) ARGFAIL("bssm_pf_run: theta must hold (phi, sigma_x, sigma_y) or (lambda, gamma, n_total, s0, i0)");
     if (T > 0 && !cfg->y) ARGFAIL("bssm_pf_run: y is NULL");
     if (!res->state_est || !res->ess || !res->loglike || (T > 0 && !res->loglike_history)) ARGFAIL("bssm_pf_run: result buffers missing");

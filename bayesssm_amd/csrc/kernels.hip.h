@@ -2009,6 +2009,128 @@ __device__ __forceinline__ void multinomial_block(double* sh4, const int bidx, c
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_multinomial_r: resample_multinomial_cpp in R's own stream (parity mode).  src/resampling.cpp:5-13 draws through
+// Rcpp::sample(n, n, true, prob) -- third-party (Rcpp sugar sample.h, mirroring R's do_sample): Normalize (p /= sum(p)),
+// then Walker's alias method when more than 200 categories have n p > 0.1, sorted inversion (Rf_revsort + cumsum)
+// otherwise.  Both set-ups are sequential algorithms whose exact order of operations decides the result, so ONE lane runs
+// them as published; the n draws (one unif_rand() each, an input here) are then taken by all lanes.  One workgroup: this
+// is the parity path (R-seeded shims and filters), not the throughput path (k_multinomial, inverse CDF).
+// ---------------------------------------------------------------------------
+__device__ __attribute__((noinline)) void revsort_dev(double* a, int* ib, int n)
+{   // R's revsort (src/main/sort.c): heapsort into decreasing order, ib[] alongside
+    int l, j, ir, i, ii;
+    double ra;
+    if (n <= 1) return;
+    a--; ib--;
+    l = (n >> 1) + 1;
+    ir = n;
+    for (;;) {
+        if (l > 1) { l = l - 1; ra = a[l]; ii = ib[l]; }
+        else {
+            ra = a[ir]; ii = ib[ir];
+            a[ir] = a[1]; ib[ir] = ib[1];
+            if (--ir == 1) { a[1] = ra; ib[1] = ii; return; }
+        }
+        i = l; j = l << 1;
+        while (j <= ir) {
+            if (j < ir && a[j] > a[j + 1]) ++j;
+            if (ra > a[j]) { a[i] = a[j]; ib[i] = ib[j]; j += (i = j); }
+            else j = ir + 1;
+        }
+        a[i] = ra; ib[i] = ii;
+    }
+}
+
+constexpr int NTM = 1024;
+__global__ __launch_bounds__(NTM) void k_multinomial_r(const double* __restrict__ w, int n, const double* __restrict__ u_base,
+                                                       long long u_stride, int* __restrict__ anc_base, long long anc_stride,
+                                                       double* __restrict__ q /* [n] */, int* __restrict__ a /* [n] */,
+                                                       int* __restrict__ HL /* [n] */, DevState* st)
+{
+    __shared__ int walker;
+    if (st->dead || !st->do_resample || st->flags) return;
+    const int call = st->cur_call;
+    const double* U = u_base + (long long)call * u_stride;
+    int* ans = anc_base + (long long)call * anc_stride;
+    if (threadIdx.x == 0) {
+        double total = 0.0;                                            // sum(weights)                    src/resampling.cpp:7
+        for (int i = 0; i < n; i++) total += w[i];
+        if (total == 0.0) { atomicOr(&st->flags, FLAG_ZERO_SUM); walker = -1; }
+        else if (!isfinite(total)) { atomicOr(&st->flags, FLAG_NONFINITE); walker = -1; }
+        else {
+            double sum = 0.0;
+            for (int i = 0; i < n; i++) { const double p = w[i] / total; q[i] = p; sum += p; }      // prob = weights / total (:10); Normalize(): sum
+            int nc = 0;
+            for (int i = 0; i < n; i++) { const double p = q[i] / sum; q[i] = p; nc += ((double)n * p > 0.1); }
+            walker = nc > 200;
+            if (nc > 200) {                                            // WalkerSample set-up
+                int H = -1, L = n;
+                for (int i = 0; i < n; i++) { a[i] = 0; q[i] = q[i] * n; if (q[i] < 1.0) HL[++H] = i; else HL[--L] = i; }
+                if (H >= 0 && L < n) {
+                    for (int k = 0; k < n - 1; k++) {
+                        const int i = HL[k], j = HL[L];
+                        a[i] = j;
+                        q[j] += q[i] - 1;
+                        L += (q[j] < 1.0);
+                        if (L >= n) break;
+                    }
+                }
+                for (int i = 0; i < n; i++) q[i] += i;
+            } else {                                                   // SampleReplace set-up
+                for (int i = 0; i < n; i++) a[i] = i + 1;
+                revsort_dev(q, a, n);
+                for (int i = 1; i < n; i++) q[i] += q[i - 1];
+            }
+        }
+    }
+    __syncthreads();
+    if (walker < 0) return;
+    // (the set-up lane's plain stores are visible to its own workgroup after the barrier: same CU, write-through L1)
+    for (int i = threadIdx.x; i < n; i += NTM) {
+        if (walker) {
+            const double rU = U[i] * n;
+            const int k = (int)rU;
+            ans[i] = (rU < q[k]) ? k + 1 : a[k] + 1;
+        } else {
+            const double rU = U[i];
+            int j = 0;
+            for (; j < n - 1; j++) if (rU <= q[j]) break;
+            ans[i] = a[j];
+        }
+    }
+}
+
+// particles[indices, ] for indices already in HBM (1-based), with the state-estimate partials (R/resampling.R:20,40,60)
+__global__ __launch_bounds__(NT) void k_gather_anc(const int* __restrict__ anc_base, long long anc_stride, int n, const double* __restrict__ xsrc,
+                                                   double* __restrict__ xdst, int dim, long long xstride, const double* __restrict__ auxsrc,
+                                                   double* __restrict__ auxdst, double* __restrict__ se_part, DevState* st)
+{
+    __shared__ double sh4[4];
+    if (st->dead || !st->do_resample || st->flags) return;
+    const int* anc = anc_base + (long long)st->cur_call * anc_stride;
+    const double invN = 1.0 / (double)n;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < EL; r++) {
+        const long long i = (long long)blockIdx.x * EB + threadIdx.x + NT * r;
+        if (i < n) {
+            const long long src = anc[i] - 1;
+            if (xdst) {
+                const double x0 = xsrc[src];
+                xdst[i] = x0; acc0 += x0 * invN;
+                if (dim > 1) { const double x1 = xsrc[xstride + src]; xdst[xstride + i] = x1; acc1 += x1 * invN; }
+            }
+            if (auxdst) auxdst[i] = auxsrc[src];
+        }
+    }
+    if (se_part) {
+        acc0 = block_sum(acc0, sh4);
+        if (dim > 1) acc1 = block_sum(acc1, sh4);
+        if (threadIdx.x == 0) { se_part[(long long)blockIdx.x * dim] = acc0; if (dim > 1) se_part[(long long)blockIdx.x * dim + 1] = acc1; }
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_multinomial(const double* __restrict__ cum, long long nw, int n, ApplyArgs a, DevState* st)
 {
     __shared__ double sh4[4];

@@ -212,8 +212,7 @@ def _r_seeded_bootstrap(y, N, model, theta, obs_times, ra, rf, threshold, return
     from .rrng import r_seeded_draws
     if model not in ("lg", "ar1sin"):
         raise ValueError("r_seed: the scalar Gaussian-observation models only (closures of the README's form)")
-    if rf == "multinomial":
-        raise ValueError("r_seed: the reference's multinomial resampler goes through Rcpp::sample, whose stream is not restated")
+    rf_dev = "multinomial_r" if rf == "multinomial" else rf      # Rcpp::sample's own algorithm on R's unif_rand() stream
     if ctl.get("draws") is not None:
         raise ValueError("r_seed and draws are mutually exclusive")
     T = int(np.asarray(y).size)
@@ -221,7 +220,7 @@ def _r_seeded_bootstrap(y, N, model, theta, obs_times, ra, rf, threshold, return
     ctl = {k: v for k, v in ctl.items() if k not in ("seed", "stream", "draws")}
     for _ in range(T + 1):
         d = r_seeded_draws(r_seed, T, int(N), rf, dec, obs_times)
-        res = particle_filter_core(y, N, model, theta, "BPF", obs_times, ra, rf, threshold, return_particles, draws=d, **ctl)
+        res = particle_filter_core(y, N, model, theta, "BPF", obs_times, ra, rf_dev, threshold, return_particles, draws=d, **ctl)
         got = np.asarray(res["_extras"]["resampled"], dtype=bool)
         early = res["_extras"]["early_return_step"]
         upto = (early - 1) if early else T                    # after a degenerate early return nothing more is drawn

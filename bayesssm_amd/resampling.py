@@ -10,8 +10,9 @@ from .rrng import RRandom
 
 # R's global generator (Mersenne-Twister, R's own seeding): after set_seed(s) the shims draw the uniforms that
 # R::runif / Rcpp::runif draw after set.seed(s) (src/resampling.cpp:28,55), so systematic and stratified ancestors are
-# the ones the reference returns for that seed.  (Multinomial: the reference goes through Rcpp::sample, a different
-# algorithm -- same law, not the same stream.)
+# the ones the reference returns for that seed.  Multinomial: the reference goes through Rcpp::sample(n, n, true, prob)
+# (src/resampling.cpp:11); after set_seed(s) the shim runs that function's published algorithm (Walker alias / sorted
+# inversion, BSSM_MULTINOMIAL_R) on R's unif_rand() stream.  With explicit draws U it is the inverse-CDF resampler.
 _rng = RRandom(int(np.random.default_rng().integers(1, 2 ** 31 - 1)))
 
 
@@ -64,12 +65,20 @@ def resample_stratified_cpp(n, weights, U=None, ctx=None, **kw):
     return _resample("stratified", n, weights, U, ctx, **kw)
 
 
-def resample_multinomial_cpp(n, weights, U=None, ctx=None, **kw):
-    """resample_multinomial_cpp(n, weights) (src/resampling.cpp:5-13); inverse-CDF draws
-    (distributional parity with Rcpp::sample only)."""
+def resample_multinomial_cpp(n, weights, U=None, ctx=None, method=None, **kw):
+    """resample_multinomial_cpp(n, weights) (src/resampling.cpp:5-13).
+    method = "rcpp" (default without U): Rcpp::sample's own algorithm as published -- Walker's alias method when more than
+    200 categories have n p > 0.1, sorted inversion otherwise -- on the unif_rand() stream (after set_seed(s): what the
+    reference draws after set.seed(s); follows the published algorithm, not a run of R);
+    method = "inverse_cdf" (default with explicit U): inverse CDF on the exact cumulative sum (same law, the throughput
+    path's resampler)."""
+    if method is None:
+        method = "rcpp" if U is None else "inverse_cdf"
+    if method not in ("rcpp", "inverse_cdf"):
+        raise ValueError("method must be 'rcpp' or 'inverse_cdf'")
     if U is None:
         U = _rng.runif(int(n))
-    return _resample("multinomial", n, weights, U, ctx, **kw)
+    return _resample("multinomial_r" if method == "rcpp" else "multinomial", n, weights, U, ctx, **kw)
 
 
 def _shim(cpp, particles, weights, U, ctx):

@@ -151,7 +151,7 @@ def r_seeded_draws(seed, T, N, resample_fn, resampled, obs_times=None):
     form (README.md:137-146: init_fn = rnorm(num_particles), transition_fn = ... + rnorm(length(particles), 0, sigma_x),
     no draws in log_likelihood_fn), in R's order (R/particle_filter_core.R:76,127,220-221 -> src/resampling.cpp:28,55):
         rnorm(N);  per observation: rnorm(N) per transition call, then -- only if that observation resamples --
-        Rcpp::runif(N) (stratified) or R::runif(1) (systematic).
+        Rcpp::runif(N) (stratified), R::runif(1) (systematic) or the N unif_rand() calls of Rcpp::sample (multinomial).
     `resampled[i]` says whether observation i+1 resamples (it decides whether uniforms are consumed there).
     Returns the `draws` dict of the filters' parity mode."""
     g = RRandom(seed)
@@ -164,8 +164,8 @@ def r_seeded_draws(seed, T, N, resample_fn, resampled, obs_times=None):
             z_trans.append(rnorm_vec(g, N))
         prev = ot
         if resampled[i]:
-            u_res.append(g.runif(N) if resample_fn == "stratified" else np.array([g.unif_rand()]))
-    nu = N if resample_fn == "stratified" else 1
+            u_res.append(g.runif(N) if resample_fn != "systematic" else np.array([g.unif_rand()]))
+    nu = N if resample_fn != "systematic" else 1
     zt = np.array(z_trans).reshape(-1, N) if z_trans else np.zeros((1, N))
     ur = np.array(u_res).reshape(-1, nu) if u_res else np.zeros((1, nu))
     # the filter indexes u_res by resample CALL, and pads to the maximum number of calls

@@ -65,7 +65,9 @@ extern "C" {
 
 #define BSSM_STRATIFIED 0
 #define BSSM_SYSTEMATIC 1
-#define BSSM_MULTINOMIAL 2
+#define BSSM_MULTINOMIAL 2    /* inverse CDF on the exact cum_sum: the reference's law, not Rcpp::sample's stream (throughput mode) */
+#define BSSM_MULTINOMIAL_R 3  /* Rcpp::sample(n, n, true, prob) as published (Walker alias / sorted inversion), U = its unif_rand()
+                                 stream: the reference's own draws for R's seed (parity mode; sequential set-up, one workgroup) */
 
 #define BSSM_TR_IDENTITY 0
 #define BSSM_TR_LOG 1

@@ -44,7 +44,7 @@
 enum { ORC_MODEL_LG = 0, ORC_MODEL_AR1SIN = 1, ORC_MODEL_SIR = 2 };
 enum { ORC_BPF = 0, ORC_APF = 1, ORC_RMPF = 2 };
 enum { ORC_SIS = 0, ORC_SISR = 1, ORC_SISAR = 2 };
-enum { ORC_STRATIFIED = 0, ORC_SYSTEMATIC = 1, ORC_MULTINOMIAL = 2 };
+enum { ORC_STRATIFIED = 0, ORC_SYSTEMATIC = 1, ORC_MULTINOMIAL = 2, ORC_MULTINOMIAL_R = 3 /* Rcpp::sample as published */ };
 
 /* ------------------------------------------------------------------------- */
 /* Resamplers: src/resampling.cpp                                             */
@@ -330,10 +330,12 @@ static double orc_rsum(int n, const double *x)
     return (double)s;
 }
 
+int orc_resample_multinomial_rcpp(int n, const double *w, int nw, const double *U, int *out, int *used_walker);
 static int orc_resample_dispatch(int kind, int N, const double *w, const double *u, int *idx)
 {
     if (kind == ORC_SYSTEMATIC) return orc_resample_systematic(N, w, N, u[0], idx, NULL);
     if (kind == ORC_STRATIFIED) return orc_resample_stratified(N, w, N, u, idx, NULL);
+    if (kind == ORC_MULTINOMIAL_R) return orc_resample_multinomial_rcpp(N, w, N, u, idx, NULL);
     return orc_resample_multinomial(N, w, N, u, idx);
 }
 
@@ -730,3 +732,96 @@ int orc_pmmh_chain(orc_pmmh_args *a)
 
 /* eigen-decomposition exposed for its own known-answer tests */
 void orc_eigen_sym_test(int p, const double *S, double *ev, double *vec) { orc_eigen_sym(p, S, ev, vec); }
+
+/* ------------------------------------------------------------------------- */
+/* resample_multinomial_cpp in R's own stream: Rcpp::sample(n, n, true, prob)  */
+/* ------------------------------------------------------------------------- */
+/* src/resampling.cpp:5-13 calls Rcpp::sample, third-party (Rcpp, unpinned, NOT under /root/reference).  Its published
+ * algorithm (Rcpp sugar sample.h, which mirrors R's src/main/random.c do_sample with replacement and unequal
+ * probabilities) is restated here; it is NOT checked against a run of R ("parity unpinned", no R in this environment):
+ *   Normalize():  p[i] /= sum(p)                       (plain double sum, index order; the second normalisation: the
+ *                                                        reference already passed prob = weights / total_weight)
+ *   nc = #{i : n p[i] > 0.1};  nc > 200 -> WalkerSample (Walker's alias method), else SampleReplace (sorted inversion)
+ *   SampleReplace: perm = 1..n; Rf_revsort(p, perm) (heapsort, decreasing); p <- cumsum(p);
+ *                  each draw: rU = unif_rand(); first j < n-1 with rU <= p[j] (else n-1); ans = perm[j]
+ *   WalkerSample:  q[i] = n p[i]; small (q < 1) indices stacked from the front of HL, large from the back;
+ *                  pair them off (a[i] = j; q[j] += q[i] - 1; ...); q[i] += i;
+ *                  each draw: rU = unif_rand() n; k = (int) rU; ans = (rU < q[k]) ? k : a[k]   (+1: one-based)
+ * U[0..n) are the unif_rand() values in draw order (an INPUT, like every draw in this file). */
+static void orc_revsort(double *a, int *ib, int n)
+{   /* R's revsort (src/main/sort.c): heapsort into DEcreasing order, ib[] alongside */
+    int l, j, ir, i, ii;
+    double ra;
+    if (n <= 1) return;
+    a--; ib--;
+    l = (n >> 1) + 1;
+    ir = n;
+    for (;;) {
+        if (l > 1) { l = l - 1; ra = a[l]; ii = ib[l]; }
+        else {
+            ra = a[ir]; ii = ib[ir];
+            a[ir] = a[1]; ib[ir] = ib[1];
+            if (--ir == 1) { a[1] = ra; ib[1] = ii; return; }
+        }
+        i = l; j = l << 1;
+        while (j <= ir) {
+            if (j < ir && a[j] > a[j + 1]) ++j;
+            if (ra > a[j]) { a[i] = a[j]; ib[i] = ib[j]; j += (i = j); }
+            else j = ir + 1;
+        }
+        a[i] = ra; ib[i] = ii;
+    }
+}
+
+int orc_resample_multinomial_rcpp(int n, const double *w, int nw, const double *U, int *out, int *used_walker)
+{
+    if (n < 0 || nw < 0) return ORC_ERR_ARG;
+    if (n != nw) return ORC_ERR_ARG;                 /* Rcpp::sample: "probs.size() != n!" -- the reference always passes n == length(weights) */
+    double *p = (double *)malloc(sizeof(double) * (size_t)(nw > 0 ? nw : 1));
+    int st = orc_validate_and_prob(nw, w, p, NULL);                  /* src/resampling.cpp:6-10 */
+    if (st != ORC_OK) { free(p); return st; }
+    double sum = 0.0;                                                  /* Normalize() */
+    for (int i = 0; i < n; i++) sum += p[i];
+    for (int i = 0; i < n; i++) p[i] /= sum;
+    int nc = 0;
+    for (int i = 0; i < n; i++) nc += (n * p[i] > 0.1);
+    if (used_walker) *used_walker = nc > 200;
+    if (nc > 200) {                                                    /* WalkerSample */
+        double *q = (double *)malloc(sizeof(double) * (size_t)n);
+        int *a = (int *)malloc(sizeof(int) * (size_t)n), *HL = (int *)malloc(sizeof(int) * (size_t)n);
+        for (int i = 0; i < n; i++) a[i] = 0;
+        int H = -1, L = n;                                             /* H = HL.begin() - 1, L = HL.begin() + n */
+        for (int i = 0; i < n; i++) { q[i] = p[i] * n; if (q[i] < 1.0) HL[++H] = i; else HL[--L] = i; }
+        if (H >= 0 && L < n) {
+            for (int k = 0; k < n - 1; k++) {
+                const int i = HL[k], j = HL[L];
+                a[i] = j;
+                q[j] += q[i] - 1;
+                L += (q[j] < 1.0);
+                if (L >= n) break;
+            }
+        }
+        for (int i = 0; i < n; i++) q[i] += i;
+        for (int i = 0; i < n; i++) {
+            const double rU = U[i] * n;
+            const int k = (int)rU;
+            out[i] = (rU < q[k]) ? k + 1 : a[k] + 1;
+        }
+        free(q); free(a); free(HL);
+    } else {                                                           /* SampleReplace */
+        int *perm = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+        for (int i = 0; i < n; i++) perm[i] = i + 1;
+        orc_revsort(p, perm, n);
+        for (int i = 1; i < n; i++) p[i] += p[i - 1];
+        const int nm1 = n - 1;
+        for (int i = 0; i < n; i++) {
+            const double rU = U[i];
+            int j;
+            for (j = 0; j < nm1; j++) if (rU <= p[j]) break;
+            out[i] = perm[j];
+        }
+        free(perm);
+    }
+    free(p);
+    return ORC_OK;
+}

@@ -23,7 +23,7 @@ ERROR_STRINGS = {
 MODEL = {"lg": 0, "ar1sin": 1, "sir": 2}
 ALGORITHM = {"BPF": 0, "APF": 1, "RMPF": 2}
 RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
-RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2}
+RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2, "multinomial_r": 3}
 TRANSFORM = {"identity": 0, "log": 1, "logit": 2}
 
 
@@ -293,3 +293,18 @@ def eigen_sym(S):
     ev, vec = np.zeros(p), np.zeros((p, p))
     lib().orc_eigen_sym_test(C.c_int(p), _p(S), _p(ev), _p(vec))
     return ev, vec
+
+
+def resample_multinomial_rcpp(n, weights, U):
+    """resample_multinomial_cpp (src/resampling.cpp:5-13) through the published algorithm of Rcpp::sample(n, n, true, prob):
+    Walker alias when more than 200 categories have n p > 0.1, sorted inversion otherwise; U = the unif_rand() stream."""
+    w, U = _d(weights), _d(U)
+    assert len(U) >= n
+    out = np.empty(n, dtype=np.int32)
+    walker = C.c_int(0)
+    st = lib().orc_resample_multinomial_rcpp(C.c_int(n), _p(w), C.c_int(len(w)), _p(U), _p(out), C.byref(walker))
+    if st == ERR_ARG:
+        raise ValueError("probs.size() != n!")
+    if st:
+        raise ResampleError(st)
+    return out, bool(walker.value)

@@ -426,3 +426,23 @@ def test_device_normals_recomputed_on_host(B, ctx, oracle):
         rad = np.sqrt(-2.0 * np.log(u1))
         want[2 * pair], want[2 * pair + 1] = rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)
     np.testing.assert_allclose(d, want, rtol=2e-14, atol=2e-15)
+
+
+@pytest.mark.parametrize("ra", ["SISR", "SISAR"])
+def test_r_seeded_bootstrap_filter_multinomial(B, ctx, oracle, ra):
+    """bootstrap_filter(resample_fn = "multinomial", r_seed = s): R's stream through Rcpp::sample's published algorithm
+    (Walker alias at N = 300, sorted inversion at N = 100), against the oracle on the same draws."""
+    from bayesssm_amd.rrng import readme_series, r_seeded_draws
+    _, ys = readme_series()
+    m = B.models.ar1_sin()
+    for N in (100, 300):
+        res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm=ra,
+                                 resample_fn="multinomial", r_seed=1405, ctx=ctx, return_ancestors=True,
+                                 phi=0.8, sigma_x=1.0, sigma_y=0.5)
+        dec = res["_extras"]["r_seed_decisions"]
+        d = r_seeded_draws(1405, 20, N, "multinomial", dec)
+        ref = oracle.pf_run("ar1sin", (0.8, 1.0, 0.5), ys, N, d["z_init"], d["z_trans"], d["u_res"], resample_algorithm=ra,
+                            resample_fn="multinomial_r", return_particles=True, return_ancestors=True)
+        _compare(res, ref, N)
+        anc = res["_extras"]["ancestors"]
+        assert anc.shape == ref["ancestors"].shape and (anc == ref["ancestors"]).mean() > 0.99

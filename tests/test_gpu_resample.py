@@ -206,3 +206,41 @@ def test_set_seed_draws_r_uniforms(B, ctx, oracle):
     B.set_seed(7)
     B.resample_stratified_cpp(3, [1.0, 1.0, 1.0], ctx=ctx)
     assert (B.resample_systematic_cpp(5000, w2, ctx=ctx) == oracle.resample_systematic(5000, w2, g.unif_rand())).all()
+
+
+@pytest.mark.parametrize("n,shape", [(5, "kat"), (64, "rand"), (200, "rand"), (201, "flat"), (1000, "cubic"), (4099, "flat"),
+                                     (500, "few"), (300, "ties"), (50, "onehot"), (20000, "cubic")])
+def test_multinomial_r_matches_oracle(B, ctx, oracle, n, shape):
+    """BSSM_MULTINOMIAL_R: Rcpp::sample(n, n, true, prob) as published (sorted inversion up to 200 'large' categories,
+    Walker alias beyond) on the same unif_rand() stream -- every index equal to the oracle's restatement, both methods."""
+    rng = np.random.default_rng(n)
+    w = {"kat": np.array([.1, .5, .1, .15, .15]), "rand": rng.random(n), "flat": rng.random(n) + 0.5, "cubic": rng.random(n) ** 3,
+         "few": np.r_[rng.random(150) + 1.0, np.full(max(n - 150, 0), 1e-9)], "ties": np.repeat(rng.random(30), 10),
+         "onehot": np.eye(1, n, 17).ravel()}[shape]
+    U = rng.random(n)
+    got = B.resample_multinomial_cpp(n, w, U=U, ctx=ctx, method="rcpp")
+    want, walker = oracle.resample_multinomial_rcpp(n, w, U)
+    assert (got == want).all()
+    assert walker == (shape in ("flat", "cubic") and n > 200 or shape == "ties")
+
+
+def test_multinomial_r_seeded_shim_and_errors(B, ctx, oracle):
+    """after set_seed(s) the shim draws R's unif_rand() stream (rrng.py) and runs Rcpp::sample's algorithm on it"""
+    from bayesssm_amd.rrng import RRandom
+    w = np.array([.1, .5, .1, .15, .15])
+    B.set_seed(1)
+    got = B.resample_multinomial_cpp(5, w, ctx=ctx)
+    want, _ = oracle.resample_multinomial_rcpp(5, w, RRandom(1).runif(5))
+    assert (got == want).all()
+    with pytest.raises(ValueError, match="Weights must be non-negative"):
+        B.resample_multinomial_cpp(3, [0.5, -0.1, 0.6], ctx=ctx)
+    with pytest.raises(ValueError, match="Sum of weights must be greater than 0"):
+        B.resample_multinomial_cpp(3, [0.0, 0.0, 0.0], ctx=ctx)
+    with pytest.raises(Exception, match="probs.size"):
+        B.resample_multinomial_cpp(4, [0.5, 0.2, 0.3], ctx=ctx)
+    # the R-level shim (R/resampling.R:13-29): particles[indices]
+    B.set_seed(7)
+    parts = np.arange(10.0, 15.0)
+    out = B.resample_multinomial(parts, w, ctx=ctx)
+    want, _ = oracle.resample_multinomial_rcpp(5, w, RRandom(7).runif(5))
+    assert (out == parts[want - 1]).all()
