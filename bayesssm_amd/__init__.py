@@ -5,7 +5,7 @@ the work runs in hand-written HIP kernels behind the C ABI of include/bayesssm_a
 Importing this package does not touch the GPU; the first call does, and fails loudly if the
 HIP library or a device is missing (there is no CPU fallback)."""
 from . import models
-from .diagnostics import ess, rhat
+from .diagnostics import PmmhOutput, ess, rhat, summary
 from .filters import (auxiliary_filter, auxiliary_filter_batch, batch_max_particles, bootstrap_filter, bootstrap_filter_batch, dump_draws,
                       particle_filter_core, resample_move_filter, resample_move_filter_batch)
 from .pmmh import (default_tune_control, pmmh, prior_exponential, prior_flat, prior_halfnormal, prior_normal,
@@ -15,7 +15,7 @@ from .resampling import (resample_multinomial, resample_multinomial_cpp, resampl
 from ._lib import BssmError, Context, default_context
 
 __all__ = [
-    "models", "ess", "rhat", "auxiliary_filter", "bootstrap_filter", "bootstrap_filter_batch", "auxiliary_filter_batch", "resample_move_filter_batch", "batch_max_particles", "resample_move_filter", "particle_filter_core", "dump_draws",
+    "models", "ess", "rhat", "summary", "PmmhOutput", "auxiliary_filter", "bootstrap_filter", "bootstrap_filter_batch", "auxiliary_filter_batch", "resample_move_filter_batch", "batch_max_particles", "resample_move_filter", "particle_filter_core", "dump_draws",
     "default_tune_control", "pmmh", "prior_exponential", "prior_flat", "prior_halfnormal", "prior_normal", "prior_uniform",
     "resample_multinomial", "resample_multinomial_cpp", "resample_stratified", "resample_stratified_cpp",
     "resample_systematic", "resample_systematic_cpp", "set_seed", "BssmError", "Context", "default_context",

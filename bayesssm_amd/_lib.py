@@ -93,12 +93,15 @@ def load():
     lib.bssm_ctx_destroy.restype = None
     lib.bssm_ctx_synchronize.argtypes = [C.c_void_p]
     lib.bssm_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
+    lib.bssm_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.bssm_ctx_get_stamps.argtypes = [C.c_void_p, C.c_void_p]
     lib.bssm_ctx_get_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bssm_resample_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bssm_resample_systematic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
     lib.bssm_resample_stratified.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.bssm_resample_multinomial.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.bssm_resample_multinomial_r.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.bssm_resample_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bssm_resample_device_status.argtypes = [C.c_void_p]
@@ -121,7 +124,8 @@ EXPORTED_SYMBOLS = [
     "bssm_ctx_synchronize", "bssm_ctx_stream", "bssm_resample_systematic", "bssm_resample_stratified",
     "bssm_resample_multinomial", "bssm_resample_device", "bssm_resample_device_status", "bssm_resample_ex",
     "bssm_pf_run", "bssm_pf_noise_shape", "bssm_dump_normals", "bssm_dump_uniforms", "bssm_dump_move_draws",
-    "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_pmmh_chain",
+    "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_ctx_set_option", "bssm_ctx_get_stamps", "bssm_pmmh_chain",
+    "bssm_resample_multinomial_r",
     "bssm_pf_run_batch", "bssm_pf_batch_max_particles", "bssm_pmmh_chains_batch", "bssm_pmmh_chain_draws",
 ]
 
@@ -153,6 +157,12 @@ class Context:
 
     def synchronize(self):
         check(load().bssm_ctx_synchronize(self._h))
+
+    OPTIONS = {"record_window": 1, "batch_literal_max": 2, "stage_expansion": 3, "inkernel_resolve": 4, "debug_stop": 5}
+
+    def set_option(self, name, value):
+        """per-context test aid / A/B switch (include/bayesssm_amd.h BSSM_OPT_*)"""
+        check(load().bssm_ctx_set_option(self._h, self.OPTIONS[name], int(value)))
 
     def set_profile(self, enable):
         check(load().bssm_ctx_set_profile(self._h, 1 if enable else 0))

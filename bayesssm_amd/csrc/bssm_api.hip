@@ -48,6 +48,12 @@ struct bssm_ctx {
     uint64_t* cin = nullptr;
     DevState* st = nullptr;
     unsigned long long* gmax_cur = nullptr;   // slot of the grid-wide max(log-weights) of the weight evaluation in flight
+    // per-context options (bssm_ctx_set_option): test aids and A/B switches -- no process-global state
+    int opt_window = 0;            // > 0: override the validity window of the scan records (ulps); a tiny window drives the literal fallbacks
+    int opt_batch_lit_max = 384;   // largest N that takes the in-order exact sums in k_pf_batch
+    int opt_stage = 1;             // LDS staging of k_apply's particle stores
+    int opt_inkernel_resolve = 1;  // grids of <= 2 NT blocks: resolve inside the consuming kernels instead of k_resolve launches
+    int opt_debug_stop = 0;        // DEV builds: stage stamps (99 typical block, 98 head block, 97 batched kernel)
     // growable buffers
     std::map<std::string, std::pair<void*, size_t>> pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -182,24 +188,27 @@ extern "C" int bssm_ctx_synchronize(bssm_ctx* c)
 
 extern "C" void* bssm_ctx_stream(bssm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-// Development aid (tools/ only, not part of the ABI in include/): scan kernels return after stage N.
-static int g_debug_stop = 0;
-extern "C" void bssm_debug_set_stop(int stage) { g_debug_stop = stage; }
-// Test aid: override the validity window of the scan records (ulps).  A tiny window makes the per-lane
-// verification fail almost everywhere, which drives the literal fallbacks of the real kernels.
-static int g_inkernel_resolve = 1;      // dev knob (A/B): resolve inside the consuming kernels vs k_resolve launches
-extern "C" void bssm_debug_set_inkernel_resolve(int on) { g_inkernel_resolve = on; }
-static int g_stage = 1;                 // dev knob: LDS staging of k_apply's particle stores
-extern "C" void bssm_debug_set_stage(int on) { g_stage = on; }
-static int g_debug_lim = 0;
-extern "C" void bssm_debug_set_window(int lim) { g_debug_lim = lim; }
-__global__ void k_set_debug(DevState* st, int v) { st->debug_stop = v; }
-extern "C" int bssm_debug_get_stamps(bssm_ctx* c, long long* out /* [4][16] */)
+extern "C" int bssm_ctx_set_option(bssm_ctx* c, int option, int value)
 {
+    if (!c) ARGFAIL("ctx is NULL");
+    switch (option) {
+        case BSSM_OPT_RECORD_WINDOW: c->opt_window = value; break;
+        case BSSM_OPT_BATCH_LITERAL_MAX: c->opt_batch_lit_max = value; break;
+        case BSSM_OPT_STAGE_EXPANSION: c->opt_stage = value; break;
+        case BSSM_OPT_INKERNEL_RESOLVE: c->opt_inkernel_resolve = value; break;
+        case BSSM_OPT_DEBUG_STOP: c->opt_debug_stop = value; break;
+        default: ARGFAIL("bssm_ctx_set_option: unknown option");
+    }
+    return BSSM_OK;
+}
+__global__ void k_set_debug(DevState* st, int v) { st->debug_stop = v; }
+extern "C" int bssm_ctx_get_stamps(bssm_ctx* c, long long* out /* [4][16] */)
+{   // DEV builds (make DEV=1): the clock64() stage stamps of the last run; zeros otherwise
+    if (!c || !out) ARGFAIL("bssm_ctx_get_stamps: NULL argument");
     DevState h;
-    if (hipMemcpy(&h, c->st, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    HIPCHK(hipMemcpy(&h, c->st, sizeof(h), hipMemcpyDeviceToHost));
     memcpy(out, h.stamps, sizeof(h.stamps));
-    return 0;
+    return BSSM_OK;
 }
 
 extern "C" int bssm_ctx_set_profile(bssm_ctx* c, int enable)
@@ -274,7 +283,7 @@ struct ResampleLaunch {
 static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
 {
     const int B = (int)((r.nw + EB - 1) / EB);
-    const int lim = g_debug_lim > 0 ? g_debug_lim : rec_window(r.nw);
+    const int lim = c->opt_window > 0 ? c->opt_window : rec_window(r.nw);
     const size_t shm = (size_t)B * sizeof(BlockRec);
     FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
     f.gmax = r.d_lw ? c->gmax_cur : nullptr;
@@ -296,7 +305,7 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     }
     // B <= 2 NT: the consuming kernels resolve the pass before them in every workgroup (resolve_in_block); larger grids
     // keep the single-workgroup k_resolve launches (a thread would have to hold more than two block records)
-    const bool inres = g_inkernel_resolve && B <= 2 * NT;
+    const bool inres = c->opt_inkernel_resolve && B <= 2 * NT;
     if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr);
     else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr);
     if (inres) {
@@ -316,7 +325,7 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     a.xsrc = r.xsrc; a.xdst = r.xdst; a.dim = r.dim; a.xstride = r.xstride;
     a.auxsrc = r.auxsrc; a.auxdst = r.auxdst; a.se_part = r.se_part;
     // LDS staging for the coalesced particle store: one array per thing carried to the outputs
-    a.nstage = (g_stage && r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
+    a.nstage = (c->opt_stage && r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
     const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), inres ? sizeof(ResolveSmem) : (size_t)0);
     if (r.kind == BSSM_SYSTEMATIC) { if (inres) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), B, NT, xshm, a, c->st, pb, psd); else LAUNCH(c, "k_apply<systematic>", (k_apply<1, false>), B, NT, xshm, a, c->st, pb, psd); }
     else if (r.kind == BSSM_STRATIFIED) { if (inres) LAUNCH(c, "k_apply<stratified>(+resolve<P>)", (k_apply<0, true>), B, NT, xshm, a, c->st, pb, psd); else LAUNCH(c, "k_apply<stratified>", (k_apply<0, false>), B, NT, xshm, a, c->st, pb, psd); }
@@ -340,7 +349,7 @@ static int resample_common_device(bssm_ctx* c, int kind, int n, const double* d_
 {
     const int B = (nw + EB - 1) / EB;
     LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
-    if (g_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, g_debug_stop);
+    if (c->opt_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, c->opt_debug_stop);
     LAUNCH(c, "k_bsum", k_bsum, B, NT, 0, d_w, (long long)nw, c->bsum, c->st);
     LAUNCH(c, "k_plan", k_plan, 1, NT, 0, c->bsum, B, c->ain_w, c->st);
     ResampleLaunch r;
@@ -426,6 +435,11 @@ extern "C" int bssm_resample_stratified(bssm_ctx* c, int n, const double* w, int
 extern "C" int bssm_resample_multinomial(bssm_ctx* c, int n, const double* w, int nw, const double* U, int* out)
 {
     return bssm_resample_ex(c, BSSM_MULTINOMIAL, n, w, nw, U, out, nullptr, nullptr);
+}
+
+extern "C" int bssm_resample_multinomial_r(bssm_ctx* c, int n, const double* w, int nw, const double* U, int* out)
+{
+    return bssm_resample_ex(c, BSSM_MULTINOMIAL_R, n, w, nw, U, out, nullptr, nullptr);
 }
 
 // ---- generator dumps ---------------------------------------------------------------
@@ -551,8 +565,8 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     (void)rmpf;
     const double dN = (double)N;
     const int resample_algorithm = rmpf ? BSSM_SISR : cfg->resample_algorithm;     // RMPF forces SISR (R/resample_move_filter.R:229)
-    double threshold = rmpf ? -1.0 : cfg->threshold;
-    if (threshold < 0) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
+    double threshold = rmpf ? (double)NAN : cfg->threshold;            // NaN: NULL => auto; an explicit value, negative included, is kept
+    if (isnan(threshold)) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
     int max_trans = 0, max_res = 0;
     bssm_pf_noise_shape(cfg->algorithm, T, cfg->obs_times, &max_trans, &max_res);
     const long long u_stride = (cfg->resample_fn == BSSM_SYSTEMATIC) ? 1 : N;
@@ -603,7 +617,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
 
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
-    if (g_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, g_debug_stop);
+    if (c->opt_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, c->opt_debug_stop);
     {   // t = 0  (:76-116)
         NoiseSrc ns; ns.arr = (const double*)d_zi; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
         LAUNCH(c, "k_init", k_init, B, NT, 0, X0, N, ns, separt, cfg->model, par);
@@ -709,8 +723,6 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
 
 // ---- many small filters per launch (one workgroup = one whole filter) -------------------------
 extern "C" int bssm_pf_batch_max_particles(void) { return EB; }
-static int g_batch_lit_max = 384;       // tuning knob (dev/test): largest N that takes the in-order exact sums in k_pf_batch
-extern "C" void bssm_debug_set_batch_literal_max(int n) { g_batch_lit_max = n; }
 
 extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_filters, const double* thetas,
                                  const unsigned long long* seeds, const unsigned long long* streams, bssm_pf_batch_result* res)
@@ -745,8 +757,8 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     HIPCHK(hipSetDevice(c->device));
     const double dN = (double)N;
     const int resample_algorithm = rmpf ? BSSM_SISR : cfg->resample_algorithm;      // RMPF forces SISR (R/resample_move_filter.R:229)
-    double threshold = rmpf ? -1.0 : cfg->threshold;
-    if (threshold < 0) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
+    double threshold = rmpf ? (double)NAN : cfg->threshold;            // NaN: NULL => auto; an explicit value, negative included, is kept
+    if (isnan(threshold)) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;   // :44-50
     const int nth = cfg->n_theta;
     int rc;
     // One packed upload and one packed download per call (pinned staging): at T = 20 the filter itself takes ~0.3 ms,
@@ -781,15 +793,15 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     void *d_ll = dq + q_ll, *d_se = dq + q_se, *d_ess = dq + q_ess, *d_llh = dq + q_llh, *d_dead = dq + q_dead, *d_flags = dq + q_flags, *d_res = dq + q_res;
     BatchArgs g;
     g.N = (int)N; g.T = T; g.resample_algorithm = resample_algorithm; g.resample_fn = cfg->resample_fn;
-    g.lim = g_debug_lim > 0 ? g_debug_lim : rec_window(N);
-    g.lit_max = g_batch_lit_max; g.move_sd = cfg->move_sd;
+    g.lim = c->opt_window > 0 ? c->opt_window : rec_window(N);
+    g.lit_max = c->opt_batch_lit_max; g.move_sd = cfg->move_sd;
     g.threshold = threshold; g.y = (const double*)d_y; g.obs_times = (const int*)d_ot; g.lgy = (const double*)d_lgy;
     g.theta = (const double*)d_th; g.theta_stride = nth; g.log_sy = (const double*)d_lsy; g.keys = (const PhiloxKey*)d_keys;
     g.loglike = (double*)d_ll; g.state_est = (double*)d_se; g.ess = (double*)d_ess; g.llh = (double*)d_llh;
     g.dead = (int*)d_dead; g.flags = (uint32_t*)d_flags; g.res_calls = (int*)d_res;
     g.phase_cycles = nullptr;
     void* d_ph = nullptr;
-    if (g_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 40 * 8, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 40 * 8, c->stream)); g.phase_cycles = (long long*)d_ph; }
+    if (c->opt_debug_stop == 97) { if ((rc = pool_get(c, "b_ph", 40 * 8, &d_ph))) return rc; HIPCHK(hipMemsetAsync(d_ph, 0, 40 * 8, c->stream)); g.phase_cycles = (long long*)d_ph; }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     const int alg = apf ? 1 : rmpf ? 2 : 0;
     const size_t bshm = (cfg->resample_fn == BSSM_MULTINOMIAL) ? (size_t)EB * sizeof(double) : 0;     // the exact cum_sum for the inverse-CDF search
@@ -1060,7 +1072,7 @@ extern "C" int bssm_pmmh_chains_batch(bssm_ctx* c, int n_chains, const bssm_pmmh
         const bssm_pf_config& q = cfgs[k].pf;
         if (ch[k].m != m || ch[k].T != T || ch[k].n_full != nth || q.model != pf0.model || q.algorithm != pf0.algorithm ||
             q.num_particles != pf0.num_particles || q.resample_algorithm != pf0.resample_algorithm || q.resample_fn != pf0.resample_fn ||
-            q.threshold != pf0.threshold || q.y != pf0.y || q.obs_times != pf0.obs_times)
+            !(q.threshold == pf0.threshold || (isnan(q.threshold) && isnan(pf0.threshold))) || q.y != pf0.y || q.obs_times != pf0.obs_times)
             ARGFAIL("bssm_pmmh_chains_batch: the chains must share the data, the filter settings and m");
     }
     bssm_pf_config pf = pf0;

@@ -80,7 +80,7 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
         umv = np.ascontiguousarray(draws["u_move"], dtype=np.float64)
         assert zmv.size >= T * N and umv.size >= T * N
     cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
-                        _lib.RESAMPLE_FN[resample_fn], N, T, -1.0 if threshold is None else float(threshold),
+                        _lib.RESAMPLE_FN[resample_fn], N, T, float("nan") if threshold is None else float(threshold),
                         _ptr(theta), int(theta.size), _ptr(y), _ptr(ot), int(seed), int(stream),
                         _ptr(zi), _ptr(zt), _ptr(ur), 1 if return_particles else 0, 1 if return_ancestors else 0,
                         float(move_sd), _ptr(zmv), _ptr(umv))
@@ -175,7 +175,7 @@ def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelih
     status = np.zeros(F, dtype=np.int32)
     ms = np.zeros(1)
     cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[_algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
-                        _lib.RESAMPLE_FN[resample_fn], N, T, -1.0 if threshold is None else float(threshold),
+                        _lib.RESAMPLE_FN[resample_fn], N, T, float("nan") if threshold is None else float(threshold),
                         None, int(thetas.shape[1]), _ptr(y), _ptr(ot), 0, 0, None, None, None, 0, 0, float(_move_sd), None, None)
     res = _lib.PfBatchResult(_ptr(ll), _ptr(se), _ptr(ess), _ptr(llh), _ptr(ers), _ptr(nres), _ptr(status), _ptr(ms))
     _lib.check(_lib.load().bssm_pf_run_batch(ctx.handle, C.byref(cfg), F, _ptr(thetas), _ptr(seeds), _ptr(streams),

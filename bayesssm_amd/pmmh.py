@@ -162,6 +162,69 @@ def run_pilot_chain(pf, pilot_m, pilot_n, pilot_reps, priors, proposal_sd, trans
             "pilot_theta_chain": chain, "pilot_loglike_chain": llc, "variance_estimate": pr_["variance_estimate"]}
 
 
+def run_pilot_chains_lockstep(pf_batch, inits, rngs, pilot_m, pilot_n, pilot_reps, priors, proposal_sd, transform,
+                              verbose=False, message=print):
+    """.run_pilot_chain (R/pmmh_tuning.R:111-317) for K chains at once: iteration i of every chain proposes on the host, ONE
+    batched launch runs all K proposals' filters (one workgroup each), every chain accepts or rejects; the `pilot_reps`
+    repetitions of .pilot_run (:29-64) for all K chains are one launch of K x pilot_reps filters.  Chain k consumes its own
+    generator rngs[k] in the order run_pilot_chain does and its filters carry the same (seed, stream), so every chain's
+    result equals run_pilot_chain's bit for bit.  pf_batch(thetas (F, p), n, tags (F,), chains (F,)) -> log-likelihoods."""
+    K, p = len(inits), len(priors)
+    for k in range(K):
+        lp0 = [pr(v) for pr, v in zip(priors, inits[k])]
+        if not np.all(np.isfinite(lp0)):
+            raise ValueError("Initial parameter values are invalid: some lie outside the prior support. "
+                             "Please provide valid starting values via pilot_init_params.")       # :133-138
+    cur = [np.array(inits[k], dtype=np.float64) for k in range(K)]
+    chain = np.empty((K, pilot_m, p))
+    llc = np.empty((K, pilot_m))
+    cur_ll = np.asarray(pf_batch(np.array(cur), pilot_n, [0] * K, list(range(K))), dtype=np.float64).copy()
+    for k in range(K):
+        chain[k, 0], llc[k, 0] = cur[k], cur_ll[k]
+    proposal_sd = np.resize(np.asarray(proposal_sd, dtype=np.float64), p)
+    for i in range(1, pilot_m):                                                                # for (m in 2:pilot_m) :188
+        props, lps = [], []
+        for k in range(K):
+            while True:                                                                        # :190-206
+                prop = _back_transform(_transform(cur[k], transform) + rngs[k].standard_normal(p) * proposal_sd, transform)
+                lp_prop = np.array([pr(v) for pr, v in zip(priors, prop)])
+                if np.all(np.isfinite(lp_prop)):
+                    break
+            props.append(prop); lps.append(lp_prop)
+        prop_ll = pf_batch(np.array(props), pilot_n, [i] * K, list(range(K)))
+        for k in range(K):
+            lp_cur = np.array([pr(v) for pr, v in zip(priors, cur[k])])
+            num = lps[k].sum() + prop_ll[k] + _log_jacobian(props[k], transform)
+            den = lp_cur.sum() + cur_ll[k] + _log_jacobian(cur[k], transform)
+            lar = num - den
+            if np.isnan(lar):
+                lar = -np.inf                                                                  # :248
+            if np.log(rngs[k].random()) < lar:
+                cur[k], cur_ll[k] = props[k], prop_ll[k]
+            chain[k, i], llc[k, i] = cur[k], cur_ll[k]
+    burn = pilot_m // 2                                                                        # :260
+    means, covs = [], []
+    for k in range(K):
+        post = chain[k, burn:]
+        means.append(post.mean(axis=0))
+        covs.append(np.cov(post, rowvar=False).reshape(p, p) if p > 1 else np.array([[post[:, 0].var(ddof=1)]]))
+        if verbose:
+            message("Pilot chain posterior mean:")
+            message(str(means[k]))
+    # .pilot_run for every chain: K x pilot_reps filters in one launch
+    th = np.repeat(np.array(means), pilot_reps, axis=0)
+    tags = [10_000_000 + r for _ in range(K) for r in range(pilot_reps)]
+    who = [k for k in range(K) for _ in range(pilot_reps)]
+    lls = np.asarray(pf_batch(th, pilot_n, tags, who)).reshape(K, pilot_reps)
+    out = []
+    for k in range(K):
+        pr_ = pilot_run(None, pilot_n, pilot_reps, pf_batch=lambda n, reps, _k=k: lls[_k])
+        print("Using %d particles for PMMH:" % pr_["target_n"])                                # message(), unconditional (:308)
+        out.append({"pilot_theta_mean": means[k], "pilot_theta_cov": covs[k], "target_n": pr_["target_n"],
+                    "pilot_theta_chain": chain[k], "pilot_loglike_chain": llc[k], "variance_estimate": pr_["variance_estimate"]})
+    return out
+
+
 def chain_assignment(num_chains, world_size):
     """chain c (0-based) -> rank c mod world_size: whole chains per GPU, no data-path collective."""
     return [[c for c in range(num_chains) if c % world_size == r] for r in range(world_size)]
@@ -222,7 +285,7 @@ def run_chain_device(pf_wrapper, y, m, model, n_params, init_theta, proposal_cov
     pb = np.ascontiguousarray([p.b for p in priors], dtype=np.float64)
     consts = np.ascontiguousarray(list(init_theta) + list(model_constants or ()), dtype=np.float64)
     pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM[algorithm], _lib.RESAMPLE_ALGORITHM[resample_algorithm],
-                       _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, ptr(consts), int(consts.size),
+                       _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), float("nan"), ptr(consts), int(consts.size),
                        ptr(y), ptr(ot), int(seed), 0, None, None, None, 0, 0)
     zp = np.ascontiguousarray(draws["z_prop"], dtype=np.float64) if draws is not None else None
     ua = np.ascontiguousarray(draws["u_accept"], dtype=np.float64) if draws is not None else None
@@ -270,7 +333,7 @@ def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, prop
         consts = np.ascontiguousarray(list(init_theta) + list(model_constants or ()), dtype=np.float64)
         pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM["APF" if pf_wrapper is auxiliary_filter else "BPF"],
                            _lib.RESAMPLE_ALGORITHM[resample_algorithm],
-                           _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), -1.0, ptr(consts), int(consts.size),
+                           _lib.RESAMPLE_FN[resample_fn], int(num_particles), int(T), float("nan"), ptr(consts), int(consts.size),
                            ptr(y), ptr(ot), int(seeds[k]), 0, None, None, None, 0, 0)
         cfgs.append(_lib.PmmhConfig(pf, int(m), int(n_params), ptr(init_theta), ptr(cov), ptr(tr), ptr(pk), ptr(pa),
                                     ptr(pb), int(seeds[k]), int(chain_indices[k]), 1 if return_latent_state_est else 0,
@@ -384,6 +447,7 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     pf_rf = kwargs.pop("pf_resample_fn", "stratified")
     tune_control = dict(tune_control)
 
+    print_result = bool(kwargs.pop("print_result", True))
     batch_chains = bool(kwargs.pop("batch_chains", True))     # lock-step chains in one launch per iteration when the filter fits
     owner_consts = list(owner.constants) if owner is not None else []
 
@@ -475,9 +539,44 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
             futs = {it: ex.submit(task, it) for it in items}
             return {it: futs[it].result() for it in items}
 
+    def prepare_lockstep(cs, ctx_c):
+        """prepare() for all of this rank's chains at once when the pilot's filters fit the batched kernel: the chains'
+        pilots advance in lock-step, one launch per pilot iteration for all of them (run_pilot_chains_lockstep)."""
+        from .filters import bootstrap_filter_batch
+        algorithm = "APF" if pf_wrapper is auxiliary_filter else "BPF"
+        p_ra, p_rf = tune_control["pilot_resample_algorithm"], tune_control["pilot_resample_fn"]
+        if verbose:
+            for c in cs:
+                print("Running chain %d..." % (c + 1))
+                print("Running pilot chain for tuning...")
+
+        def pf_batch(thetas, n, tags, who):
+            th = np.hstack([np.asarray(thetas, dtype=np.float64), np.tile(np.asarray(owner_consts, dtype=np.float64), (len(tags), 1))]) \
+                if owner_consts else np.asarray(thetas, dtype=np.float64)
+            r = bootstrap_filter_batch(y, int(n), init_fn, transition_fn, log_likelihood_fn, th,
+                                       [int(seeds[cs[k]]) for k in who], [(1 << 40) + int(t) for t in tags], obs_times=obs_times,
+                                       resample_algorithm=p_ra, resample_fn=p_rf, ctx=ctx_c, _algorithm=algorithm)
+            if np.any(r["status"] != 0):
+                raise ValueError(_lib.load().bssm_status_string(int(r["status"][r["status"] != 0][0])).decode())
+            return r["loglike"]
+
+        pilots = run_pilot_chains_lockstep(
+            pf_batch, [[float(pilot_init_params[c][k]) for k in prior_names] for c in cs],
+            [np.random.default_rng([int(seeds[c]), 77]) for c in cs], tune_control["pilot_m"], tune_control["pilot_n"],
+            tune_control["pilot_reps"], priors, tune_control["pilot_proposal_sd"], transform, verbose,
+            message=(print if verbose else (lambda *_: None)))
+        out = {}
+        for c, pilot in zip(cs, pilots):
+            out[c] = {"init_theta": [float(v) for v in pilot["pilot_theta_mean"]],
+                      "cov": pilot["pilot_theta_cov"] if proposal_cov is None else proposal_cov,
+                      "n": int(pilot["target_n"] if num_particles is None else num_particles), "pilot": pilot}
+        return out
+
     failure = None
     try:
-        preps = run_pool(prepare, list(mine))
+        lock = (use_pilot and batch_chains and _chain_runner is None and len(mine) > 1
+                and batch_eligible(pf_wrapper, model, tune_control["pilot_n"], tune_control["pilot_resample_fn"]))
+        preps = prepare_lockstep(list(mine), ctxs[0] if ctxs else None) if lock else run_pool(prepare, list(mine))
         results = {}
         groups = {}
         for c in mine:
@@ -525,14 +624,16 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
         mat = post[:, :, j].T                                             # iterations x chains
         diag_ess[name] = diagnostics.ess(mat) if num_chains > 1 else float("nan")
         diag_rhat[name] = diagnostics.rhat(mat)
-    result = {
+    result = diagnostics.PmmhOutput({
         "theta_chain": {"chain": np.repeat(np.arange(1, num_chains + 1), m - burn_in),
                         **{name: post[:, :, j].reshape(-1) for j, name in enumerate(prior_names)}},
         "diagnostics": {"ess": diag_ess, "rhat": diag_rhat},
         "_extras": {"local_chains": extras, "seeds": seeds, "rank": rank, "world_size": world},
-    }
+    })
     if return_latent_state_est:
         result["latent_state_chain"] = {c: extras[c]["state_est_chain"][burn_in:] for c in mine}
+    if rank == 0 and print_result:
+        print(result.format())                                               # print(result)  (R/pmmh.R:610)
     if any(np.isfinite(v) and v < 400 for v in diag_ess.values()):
         warnings.warn("Some ESS values are below 400, indicating poor mixing. "
                       "Consider running the chains for more iterations.")

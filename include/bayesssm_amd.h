@@ -94,6 +94,16 @@ int bssm_ctx_synchronize(bssm_ctx* ctx);
 /* The HIP stream (hipStream_t) all of this context's kernels are launched on. */
 void* bssm_ctx_stream(bssm_ctx* ctx);
 
+/* Per-context options: test aids and A/B switches (the library keeps no process-global mutable state besides the
+ * per-thread last-error string).  Defaults in brackets. */
+#define BSSM_OPT_RECORD_WINDOW 1       /* [0 = automatic] validity window of the exact-scan records in ulps; a tiny window forces the literal fallbacks (tests) */
+#define BSSM_OPT_BATCH_LITERAL_MAX 2   /* [384] largest N whose exact sums the batched kernel takes by the in-order pass */
+#define BSSM_OPT_STAGE_EXPANSION 3     /* [1] stage the resampled particles in LDS and store them coalesced */
+#define BSSM_OPT_INKERNEL_RESOLVE 4    /* [1] grids of <= 512 blocks: the consuming kernels resolve the pass before them; 0 = k_resolve launches */
+#define BSSM_OPT_DEBUG_STOP 5          /* [0] DEV builds (make DEV=1): stage stamps */
+int bssm_ctx_set_option(bssm_ctx* ctx, int option, int value);
+int bssm_ctx_get_stamps(bssm_ctx* ctx, long long* out /* [4][16] */);
+
 /* ---- resamplers: host-pointer form (what the R glue binds) --------------- */
 /* n outputs over nw weights (the reference always passes n == nw).
  * U: the uniform draw(s) the reference takes from R's RNG --
@@ -105,6 +115,9 @@ void* bssm_ctx_stream(bssm_ctx* ctx);
 int bssm_resample_systematic(bssm_ctx* ctx, int n, const double* weights, int nw, double U, int* indices_out);
 int bssm_resample_stratified(bssm_ctx* ctx, int n, const double* weights, int nw, const double* U, int* indices_out);
 int bssm_resample_multinomial(bssm_ctx* ctx, int n, const double* weights, int nw, const double* U, int* indices_out);
+/* Rcpp::sample(n, n, true, prob) as published (what src/resampling.cpp:11 draws): U = its n unif_rand() values in order;
+ * n must equal nw ("probs.size() != n!").  This is the form the R glue binds for _bayesSSM_resample_multinomial_cpp. */
+int bssm_resample_multinomial_r(bssm_ctx* ctx, int n, const double* weights, int nw, const double* U, int* indices_out);
 
 /* Device-pointer form: weights / U / indices already in HBM; runs on the
  * context's stream and does not synchronise.  kind = BSSM_STRATIFIED/... ;
@@ -132,7 +145,7 @@ typedef struct {
     int resample_fn;         /* BSSM_STRATIFIED / SYSTEMATIC / MULTINOMIAL     */
     long long num_particles;
     int T;                   /* number of observations                         */
-    double threshold;        /* < 0: NULL => auto (R/particle_filter_core.R:44-50) */
+    double threshold;        /* NaN: NULL => auto (R/particle_filter_core.R:44-50); any other value is used as given */
     const double* theta;     /* model parameters (host), n_theta doubles       */
     int n_theta;
     const double* y;         /* observations (host), T doubles                 */

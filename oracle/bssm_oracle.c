@@ -296,7 +296,7 @@ typedef struct {
     /* inputs */
     int model, algorithm, resample_algorithm, resample_fn;
     int N, T;
-    double threshold;       /* < 0 => NULL => auto (R/particle_filter_core.R:44-50) */
+    double threshold;       /* NaN => NULL => auto (R/particle_filter_core.R:44-50); any other value as given */
     const double *theta;    /* [3] */
     const double *y;        /* [T] */
     const int *obs_times;   /* [T] or NULL => 1..T (:71) */
@@ -345,7 +345,7 @@ int orc_pf_run(orc_pf_args *a)
     if (N <= 0 || T < 0) return ORC_ERR_ARG;                 /* assert_count(num_particles, positive) :33 */
     const double dN = (double)N;
     double threshold = a->threshold;
-    if (threshold < 0) {                                       /* :44-50 */
+    if (isnan(threshold)) {                                    /* :44-50 */
         threshold = (a->resample_algorithm == ORC_SIS) ? INFINITY
                   : (a->resample_algorithm == ORC_SISR) ? dN : dN / 2;
     }

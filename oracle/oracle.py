@@ -163,7 +163,7 @@ def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
     resampled = np.zeros(max(T, 1), dtype=np.int32)
     a = _PfArgs(MODEL[model], ALGORITHM[algorithm], RESAMPLE_ALGORITHM[resample_algorithm],
                 RESAMPLE_FN[resample_fn], N, T,
-                -1.0 if threshold is None else float(threshold),
+                float("nan") if threshold is None else float(threshold),
                 _p(theta), _p(y), _p(ot), _p(z_init), _p(z_trans), _p(u_res), int(seed), int(stream),
                 _p(state_est), _p(ess), _p(llh), _p(ll), _p(anc), _p(wh), _p(ph),
                 _p(nt), _p(nr), _p(ers), _p(resampled), float(move_sd),

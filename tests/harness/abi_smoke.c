@@ -1,6 +1,7 @@
 /* Plain-C client of include/bayesssm_amd.h (compiled with gcc, no HIP headers): what a foreign-language binding sees.
  * Prints one line per call; tests/test_gpu_abi_c.py checks them against the oracle.
  *   usage: abi_smoke   (needs a GPU) */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,7 +31,7 @@ int main(void)
     double theta[3] = {0.8, 1.0, 0.7};
     bssm_pf_config cfg; memset(&cfg, 0, sizeof cfg);
     cfg.model = BSSM_MODEL_LG; cfg.algorithm = BSSM_BPF; cfg.resample_algorithm = BSSM_SISAR; cfg.resample_fn = BSSM_STRATIFIED;
-    cfg.num_particles = N; cfg.T = T; cfg.threshold = -1.0; cfg.theta = theta; cfg.n_theta = 3; cfg.y = y; cfg.seed = 11; cfg.stream = 3;
+    cfg.num_particles = N; cfg.T = T; cfg.threshold = NAN; cfg.theta = theta; cfg.n_theta = 3; cfg.y = y; cfg.seed = 11; cfg.stream = 3;
     double se[T + 1], ess[T + 1], llh[T], ll = 0; int early = 0, nres = 0;
     bssm_pf_result res; memset(&res, 0, sizeof res);
     res.state_est = se; res.ess = ess; res.loglike_history = llh; res.loglike = &ll; res.early_return_step = &early; res.n_res_calls = &nres;

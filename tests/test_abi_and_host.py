@@ -180,3 +180,19 @@ def test_readme_series_regression():
     assert (d["u_res"][3:] == 0).all() and (d["u_res"][:3] > 0).all()
     d1 = r_seeded_draws(7, 5, 10, "systematic", [True] * 5, obs_times=[1, 3, 3, 4, 6])
     assert d1["z_trans"].shape == (6, 10) and d1["u_res"].shape == (5,)
+
+
+def test_r_glue_file_binds_declared_symbols():
+    """r/bayesssm_amd_glue.c (the `.Call` glue of INTEGRATION.md; not compilable here -- no R headers): every bssm_*
+    function it calls is declared in include/bayesssm_amd.h, the three original entry points keep their names and arity 2
+    (src/RcppExports.cpp:50-55), and <string.h> is there for its memset."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    glue = open(os.path.join(root, "r", "bayesssm_amd_glue.c")).read()
+    header = open(os.path.join(root, "include", "bayesssm_amd.h")).read()
+    assert "#include <string.h>" in glue
+    for fn in set(re.findall(r"\b(bssm_[a-z_]+)\s*\(", glue)):
+        assert re.search(r"\b%s\s*\(" % fn, header), fn
+    for name in ("multinomial", "stratified", "systematic"):
+        assert re.search(r'\{"_bayesSSM_resample_%s_cpp",\s+\(DL_FUNC\)&_bayesSSM_resample_%s_cpp, 2\}' % (name, name), glue)
+    assert "R_registerRoutines(dll, NULL, CallEntries, NULL, NULL)" in glue and "R_useDynamicSymbols(dll, FALSE)" in glue

@@ -55,14 +55,13 @@ def test_batch_in_order_and_record_paths_agree():
     y = _data(15)
     thetas = np.array([[0.8, 1.0, 0.7], [0.4, 1.3, 0.5], [0.9, 0.6, 1.0]])
     outs = []
-    try:
-        for lim in (0, 100000):
-            _lib.load().bssm_debug_set_batch_literal_max(lim)
-            outs.append([b.bootstrap_filter_batch(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 3,
-                                                  resample_algorithm="SISR", resample_fn=rf)
-                         for N in (5, 64, 333, 1500, 2048) for rf in ("systematic", "stratified")])
-    finally:
-        _lib.load().bssm_debug_set_batch_literal_max(384)
+    cx = b.Context(0, 4096, 1)
+    for lim in (0, 100000):
+        cx.set_option("batch_literal_max", lim)
+        outs.append([b.bootstrap_filter_batch(y, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, thetas, 3,
+                                              resample_algorithm="SISR", resample_fn=rf, ctx=cx)
+                     for N in (5, 64, 333, 1500, 2048) for rf in ("systematic", "stratified")])
+    cx.close()
     for a, c in zip(*outs):
         for k in ("loglike", "state_est", "ess", "loglike_history"):
             np.testing.assert_array_equal(a[k], c[k])
@@ -375,3 +374,31 @@ def test_readme_example_posterior_matches_published_table():
     assert abs(q[0] - 0.55) < 0.07 and abs(q[1] - 0.97) < 0.04
     assert abs(th["sigma_x"].mean() - 0.78) < 0.45 and abs(th["sigma_y"].mean() - 0.89) < 0.30     # README: ESS 15 and 36
     assert abs(np.quantile(th["sigma_x"], 0.975) - 1.85) < 0.3 and abs(np.quantile(th["sigma_y"], 0.975) - 1.45) < 0.3
+
+
+def test_pmmh_lockstep_pilots_equal_one_at_a_time():
+    """pmmh() with its pilot: with batch_chains the chains' pilots advance in lock-step (one launch per pilot iteration for
+    all chains, K x pilot_reps filters in one launch) and the main chains likewise; without it every filter is its own
+    multi-launch run.  Same draws, bit-identical filters: the whole output must be equal."""
+    import warnings
+    import bayesssm_amd as b
+    from bayesssm_amd.rrng import readme_series
+    _, ys = readme_series()
+    m = b.models.ar1_sin()
+    kw = dict(pf_wrapper=b.bootstrap_filter, y=ys, m=60, init_fn=m.init_fn, transition_fn=m.transition_fn,
+              log_likelihood_fn=m.log_likelihood_fn,
+              log_priors={"phi": b.prior_normal(0, 1), "sigma_x": b.prior_exponential(1), "sigma_y": b.prior_exponential(1)},
+              pilot_init_params=[{"phi": 0.8, "sigma_x": 1.0, "sigma_y": 0.5}, {"phi": 1.0, "sigma_x": 0.5, "sigma_y": 1.0},
+                                 {"phi": 0.6, "sigma_x": 0.8, "sigma_y": 0.7}],
+              burn_in=10, num_chains=3, seed=1405, param_transform={"phi": "identity", "sigma_x": "log", "sigma_y": "log"},
+              tune_control=b.default_tune_control(pilot_m=40, pilot_burn_in=5, pilot_reps=8), print_result=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = b.pmmh(batch_chains=True, **kw)
+        c = b.pmmh(batch_chains=False, chains_per_gpu=1, **kw)
+    for k in ("chain", "phi", "sigma_x", "sigma_y"):
+        assert (a["theta_chain"][k] == c["theta_chain"][k]).all()
+    for ch in range(3):
+        pa, pc = a["_extras"]["local_chains"][ch]["pilot"], c["_extras"]["local_chains"][ch]["pilot"]
+        assert pa["target_n"] == pc["target_n"] and (pa["pilot_theta_chain"] == pc["pilot_theta_chain"]).all()
+        assert (pa["pilot_theta_cov"] == pc["pilot_theta_cov"]).all()

@@ -339,7 +339,7 @@ def test_threshold_argument(B, ctx, oracle):
     ys = _simulate(rng, T)
     m = B.models.linear_gaussian()
     d = _draws(rng, oracle, "BPF", T, N, "systematic")
-    for thr in (0.0, 0.9 * N, 10.0 * N):
+    for thr in (-1.0, 0.0, 0.9 * N, 10.0 * N):       # a negative threshold is a value like any other: SISAR never resamples
         res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_fn="systematic",
                                  threshold=thr, draws=d, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
         ref = oracle.pf_run("lg", (0.8, 1.0, 1.0), ys, N, d["z_init"], d["z_trans"], d["u_res"],

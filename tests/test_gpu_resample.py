@@ -147,13 +147,11 @@ def test_proportions(B, ctx):
 
 @pytest.mark.parametrize("lim", [1, 5, 200])
 def test_fallback_paths_stay_exact(B, ctx, oracle, lim):
-    """Shrink the records' validity window (test-only knob of the library) so that the per-lane verification
+    """Shrink the records' validity window (a per-context option of the library) so that the per-lane verification
     fails and the kernels' literal fallbacks run: results must stay bit-exact."""
-    from bayesssm_amd import _lib
-    lib = _lib.load()
     rng = np.random.default_rng(lim)
     try:
-        lib.bssm_debug_set_window(lim)
+        ctx.set_option("record_window", lim)
         total_fallbacks = 0
         for n, kind in ((5000, "uniformish"), (70000, "skewed"), (300000, "uniformish"), (40000, "range")):
             w = _weights(rng, n, kind)
@@ -168,7 +166,7 @@ def test_fallback_paths_stay_exact(B, ctx, oracle, lim):
         if lim <= 5:
             assert total_fallbacks > 0, "the tiny window did not exercise any fallback"
     finally:
-        lib.bssm_debug_set_window(0)
+        ctx.set_option("record_window", 0)
 
 
 @pytest.mark.parametrize("n,distinct", [(1 << 18, 20), (1 << 20, 3), (300001, 1)])

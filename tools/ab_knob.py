@@ -1,15 +1,15 @@
-"""Dev tool: same-process A/B of a library debug knob:  python tools/ab_knob.py bssm_debug_set_draws_ahead [N] [resample_fn]"""
+"""Dev tool: same-process A/B of a per-context option:  python tools/ab_knob.py inkernel_resolve [N] [resample_fn]"""
 import sys, ctypes; sys.path.insert(0, '.')
 import numpy as np, bayesssm_amd as b
 from bayesssm_amd import _lib
 from bench import simulate_lg
 lib = _lib.load()
-knob = getattr(lib, sys.argv[1]); knob.argtypes = [ctypes.c_int]
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
 rf = sys.argv[3] if len(sys.argv) > 3 else "systematic"
 ys = simulate_lg(1000)[: (1000 if N <= 1 << 20 else 250)]
 m = b.models.linear_gaussian()
 ctx = b.Context(0, N, 1)
+knob = lambda v: ctx.set_option(sys.argv[1], v)   # noqa: E731
 def run(stream):
     return b.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm="SISR", resample_fn=rf,
                               return_particles=False, seed=1405, stream=stream, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)

@@ -8,7 +8,7 @@ rng = np.random.default_rng(1)
 n = 1 << 20
 w = np.exp(-0.5 * rng.standard_normal(n) ** 2); w /= w.sum()
 for stage in (0,):
-    lib.bssm_debug_set_stop(stage)
+    ctx.set_option('debug_stop', stage)
     ctx.set_profile(True)
     for rep in range(4):
         got, stats = b.resample_systematic_cpp(n, w, U=0.3, ctx=ctx, return_stats=True)

@@ -9,12 +9,11 @@ N = 1 << 20
 ctx = b.Context(0, N, 1)
 ys = simulate_lg(1000)[:30]
 m = b.models.linear_gaussian()
-lib.bssm_debug_set_stop(98)
-lib.bssm_debug_get_stamps.argtypes = [C.c_void_p, C.c_void_p]
+ctx.set_option('debug_stop', 98)
 r = b.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm="SISR",
                        resample_fn="systematic", return_particles=False, seed=1, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
 st = np.zeros((4, 16), dtype=np.int64)
-lib.bssm_debug_get_stamps(ctx.handle, st.ctypes.data_as(C.c_void_p))
+lib.bssm_ctx_get_stamps(ctx.handle, st.ctypes.data_as(C.c_void_p))
 for r in (0, 1): print('resolve', r, 'walk setup->loop start', st[r][10] - st[r][4], 'loop', st[r][11] - st[r][10], 'after loop -> walk end', st[r][5] - st[r][11], 'chain took', st[r][12], 'links in', st[r][13] - st[r][10])
 kw = st[2]
 print('k_weights block 100: start->prologue', kw[8]-kw[4], 'prologue->weights', kw[9]-kw[8], 'weights->scan', kw[10]-kw[9], 'scan->minmax', kw[11]-kw[10], 'total', kw[11]-kw[4])
