@@ -12,10 +12,11 @@ from .pmmh import (default_tune_control, pmmh, prior_exponential, prior_flat, pr
                    prior_uniform)
 from .resampling import (resample_multinomial, resample_multinomial_cpp, resample_stratified,
                          resample_stratified_cpp, resample_systematic, resample_systematic_cpp, set_seed)
+from .sharded import bootstrap_filter_sharded
 from ._lib import BssmError, Context, default_context
 
 __all__ = [
-    "models", "ess", "rhat", "summary", "PmmhOutput", "auxiliary_filter", "bootstrap_filter", "bootstrap_filter_batch", "auxiliary_filter_batch", "resample_move_filter_batch", "batch_max_particles", "resample_move_filter", "particle_filter_core", "dump_draws",
+    "models", "bootstrap_filter_sharded", "ess", "rhat", "summary", "PmmhOutput", "auxiliary_filter", "bootstrap_filter", "bootstrap_filter_batch", "auxiliary_filter_batch", "resample_move_filter_batch", "batch_max_particles", "resample_move_filter", "particle_filter_core", "dump_draws",
     "default_tune_control", "pmmh", "prior_exponential", "prior_flat", "prior_halfnormal", "prior_normal", "prior_uniform",
     "resample_multinomial", "resample_multinomial_cpp", "resample_stratified", "resample_stratified_cpp",
     "resample_systematic", "resample_systematic_cpp", "set_seed", "BssmError", "Context", "default_context",

@@ -48,6 +48,7 @@ struct bssm_ctx {
     uint64_t* cin = nullptr;
     DevState* st = nullptr;
     unsigned long long* gmax_cur = nullptr;   // slot of the grid-wide max(log-weights) of the weight evaluation in flight
+    int sh_boff = 0, sh_nloc = 0;  // particle-block sharding (bssm_pf_run_sharded): this rank's first block / block count; 0 = whole grid
     // per-context options (bssm_ctx_set_option): test aids and A/B switches -- no process-global state
     int opt_window = 0;            // > 0: override the validity window of the scan records (ulps); a tiny window drives the literal fallbacks
     int opt_batch_lit_max = 384;   // largest N that takes the in-order exact sums in k_pf_batch
@@ -285,13 +286,16 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     const int B = (int)((r.nw + EB - 1) / EB);
     const int lim = c->opt_window > 0 ? c->opt_window : rec_window(r.nw);
     const size_t shm = (size_t)B * sizeof(BlockRec);
+    const int boff = c->sh_boff, G = c->sh_nloc ? c->sh_nloc : B;        // launch grid: all blocks, or this rank's (sharded)
+    const int Bg = c->sh_nloc ? B : 0;                                   // global block count handed to the kernels when sharded
     FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
-    f.gmax = r.d_lw ? c->gmax_cur : nullptr;
+    f.lead = boff; f.pub = c->sh_nloc ? boff + G / 2 : B / 2;
+    f.gmax = (r.d_lw && !c->sh_nloc) ? c->gmax_cur : nullptr;       // (sharded: the partial maxima of other ranks are not in this rank's slots)
     f.ain_out = c->ain_w; f.plan = r.plan; f.N = r.nw; f.obs_i = r.obs_i; f.resample_algorithm = r.resample_algorithm;
     f.threshold = r.threshold; f.ess_out = r.d_ess; f.llh_out = r.d_llh; f.resampled_out = r.d_resampled;
     if (r.kind == BSSM_MULTINOMIAL_R) {
         // parity mode: Rcpp::sample's own algorithm on the injected unif_rand() stream; no exact scan involved
-        if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr);
+        if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
         void *dq, *da, *dh, *danc = r.d_anc;
         if (pool_get(c, "mr_q", (size_t)r.nw * 8, &dq) || pool_get(c, "mr_a", (size_t)r.nw * 4, &da) || pool_get(c, "mr_hl", (size_t)r.nw * 4, &dh)) return;
         long long astride = r.anc_stride;
@@ -306,13 +310,13 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     // B <= 2 NT: the consuming kernels resolve the pass before them in every workgroup (resolve_in_block); larger grids
     // keep the single-workgroup k_resolve launches (a thread would have to hold more than two block records)
     const bool inres = c->opt_inkernel_resolve && B <= 2 * NT;
-    if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr);
-    else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr);
+    if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
+    else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
     if (inres) {
-        LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), B, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p);
+        LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p, boff, Bg);
     } else {
         LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
-        LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), B, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec_p, c->side_p, c->st, f, nullptr, nullptr, nullptr);
+        LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), G, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec_p, c->side_p, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
         LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec_p, c->side_p, c->cin, c->ain_w, c->ain_p, c->st);
     }
     const BlockRec* pb = inres ? c->brec_p : nullptr;
@@ -325,12 +329,13 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     a.xsrc = r.xsrc; a.xdst = r.xdst; a.dim = r.dim; a.xstride = r.xstride;
     a.auxsrc = r.auxsrc; a.auxdst = r.auxdst; a.se_part = r.se_part;
     // LDS staging for the coalesced particle store: one array per thing carried to the outputs
+    a.lead = boff; a.last = boff + G - 1;
     a.nstage = (c->opt_stage && r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
     const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), inres ? sizeof(ResolveSmem) : (size_t)0);
-    if (r.kind == BSSM_SYSTEMATIC) { if (inres) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), B, NT, xshm, a, c->st, pb, psd); else LAUNCH(c, "k_apply<systematic>", (k_apply<1, false>), B, NT, xshm, a, c->st, pb, psd); }
-    else if (r.kind == BSSM_STRATIFIED) { if (inres) LAUNCH(c, "k_apply<stratified>(+resolve<P>)", (k_apply<0, true>), B, NT, xshm, a, c->st, pb, psd); else LAUNCH(c, "k_apply<stratified>", (k_apply<0, false>), B, NT, xshm, a, c->st, pb, psd); }
+    if (r.kind == BSSM_SYSTEMATIC) { if (inres) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); else LAUNCH(c, "k_apply<systematic>", (k_apply<1, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); }
+    else if (r.kind == BSSM_STRATIFIED) { if (inres) LAUNCH(c, "k_apply<stratified>(+resolve<P>)", (k_apply<0, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); else LAUNCH(c, "k_apply<stratified>", (k_apply<0, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); }
     else {
-        if (inres) LAUNCH(c, "k_apply<cum>(+resolve<P>)", (k_apply<2, true>), B, NT, xshm, a, c->st, pb, psd); else LAUNCH(c, "k_apply<cum>", (k_apply<2, false>), B, NT, xshm, a, c->st, pb, psd);
+        if (inres) LAUNCH(c, "k_apply<cum>(+resolve<P>)", (k_apply<2, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); else LAUNCH(c, "k_apply<cum>", (k_apply<2, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg);
         const int Bo = (int)(((long long)r.n + EB - 1) / EB);
         LAUNCH(c, "k_multinomial", k_multinomial, Bo, NT, 0, a.cum_out, r.nw, r.n, a, c->st);
     }
@@ -499,12 +504,13 @@ template <int MODEL>
 static void launch_step(bssm_ctx* c, bool trans, int weight, bool subaux, double* x, long long N, int B,
                         const ModelPar& par, double y, const NoiseSrc& ns)
 {
-#define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur
+    if (c->sh_nloc) B = c->sh_nloc;                  // sharded: this rank's blocks only (k_step adds the block offset)
+#define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff
     if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step<trans+weight>", (k_step<MODEL, true, 1, false>), B, NTS, 0, STEP_ARGS);
     else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step<trans+weight-aux>", (k_step<MODEL, true, 1, true>), B, NTS, 0, STEP_ARGS);
     else if (trans && weight == 0) LAUNCH(c, "k_step<trans>", (k_step<MODEL, true, 0, false>), B, NTS, 0, STEP_ARGS);
     else if (!trans && weight == 2) {
-        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NTS, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur);
+        LAUNCH(c, "k_step<aux-weight>", (k_step<MODEL, false, 2, false>), B, NTS, 0, x, x, c->auxlw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff);
     }
 #undef STEP_ARGS
 }
@@ -620,7 +626,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     if (c->opt_debug_stop) hipLaunchKernelGGL(k_set_debug, dim3(1), dim3(1), 0, c->stream, c->st, c->opt_debug_stop);
     {   // t = 0  (:76-116)
         NoiseSrc ns; ns.arr = (const double*)d_zi; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
-        LAUNCH(c, "k_init", k_init, B, NT, 0, X0, N, ns, separt, cfg->model, par);
+        LAUNCH(c, "k_init", k_init, B, NT, 0, X0, N, ns, separt, cfg->model, par, 0);
         if (cfg->return_particles) {
             // weights = rep(1/N, N): do_resample is 0 after reset, so seed row 0 from a constant fill
             std::vector<double> w0((size_t)N, 1.0 / dN);
@@ -661,8 +667,8 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
             // obs_times repeats a time: no transition, weights on the current particles
             NoiseSrc ns = noise(0);
             next_gmax();
-            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur);
-            else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur);
+            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff);
+            else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff);
             else launch_step_sir(c, false, 1, false, X0, N, B, par, yi, ns);
         }
         double* se_row = separt + (size_t)i * B * dim;
@@ -672,7 +678,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         r.xsrc = X0; r.xdst = X1; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = se_row;
         launch_scan_and_apply(c, r);
         if (resample_algorithm != BSSM_SISR)
-            LAUNCH(c, "k_carry", k_carry, B, NT, 0, X0, X1, c->w, N, dim, se_row, c->st);
+            LAUNCH(c, "k_carry", k_carry, B, NT, 0, X0, X1, c->w, N, dim, se_row, c->st, 0);
         std::swap(X0, X1);
         if (rmpf) {   // move every particle, then take the state estimate (:226-241)
             const double* zm = d_zmv ? (const double*)d_zmv + (size_t)(i - 1) * N : nullptr;
@@ -718,6 +724,186 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         HIPCHK(hipMemcpy(res->particles_history, d_ph, (size_t)rows * N * dim * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(res->weights_history, d_wh, (size_t)rows * N * 8, hipMemcpyDeviceToHost));
     }
+    return BSSM_OK;
+}
+
+// ---- one filter, particle blocks sharded over ranks (prototype) -------------------------------------------------
+// The same kernels on this rank's blocks of the global numbering (block offset), host-staged collectives at the four
+// points where a step needs the other ranks' blocks; every rank resolves the exact sums itself (resolve_in_block), so no
+// rank waits for a "resolver" and the result does not depend on the number of ranks.
+struct ShardScope {      // the context runs sharded only inside bssm_pf_run_sharded
+    bssm_ctx* c;
+    ShardScope(bssm_ctx* c_, int boff, int nloc) : c(c_) { c->sh_boff = boff; c->sh_nloc = nloc; }
+    ~ShardScope() { c->sh_boff = 0; c->sh_nloc = 0; }
+};
+
+extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const bssm_shard* sh, bssm_pf_result* res)
+{
+    if (!c || !cfg || !sh || !res) ARGFAIL("bssm_pf_run_sharded: NULL argument");
+    if (!sh->all_gather || !sh->exchange || sh->world < 1 || sh->rank < 0 || sh->rank >= sh->world) ARGFAIL("bssm_pf_run_sharded: bad shard description");
+    const long long N = cfg->num_particles;
+    const int T = cfg->T, W = sh->world;
+    if (cfg->model != BSSM_MODEL_LG && cfg->model != BSSM_MODEL_AR1SIN) ARGFAIL("bssm_pf_run_sharded: scalar-state Gaussian models only");
+    if (cfg->algorithm != BSSM_BPF) ARGFAIL("bssm_pf_run_sharded: bootstrap filter only");
+    if (cfg->resample_fn != BSSM_STRATIFIED && cfg->resample_fn != BSSM_SYSTEMATIC) ARGFAIL("bssm_pf_run_sharded: stratified / systematic resampling only");
+    if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run_sharded: unknown resample_algorithm");
+    if (cfg->return_particles || cfg->return_ancestors) ARGFAIL("bssm_pf_run_sharded: histories are not available");
+    if (N <= 0 || N % ((long long)W * EB) != 0) ARGFAIL("bssm_pf_run_sharded: num_particles must be a multiple of world x 2048");
+    const int B = (int)(N / EB), nloc = B / W, boff = sh->rank * nloc;
+    if (B > 2 * NT) { g_err = "bssm_pf_run_sharded: at most 2^20 particles (every rank resolves the block records itself)"; return BSSM_ERR_CAPACITY; }
+    if (N > c->cap) { g_err = "bssm_pf_run_sharded: num_particles exceeds context capacity"; return BSSM_ERR_CAPACITY; }
+    if (T < 0 || (T > 0 && !cfg->y) || !cfg->theta || cfg->n_theta < 3) ARGFAIL("bssm_pf_run_sharded: bad filter configuration");
+    if (!res->state_est || !res->ess || !res->loglike || (T > 0 && !res->loglike_history)) ARGFAIL("bssm_pf_run_sharded: result buffers missing");
+    HIPCHK(hipSetDevice(c->device));
+    ShardScope scope(c, boff, nloc);
+    const double dN = (double)N;
+    const int resample_algorithm = cfg->resample_algorithm;
+    double threshold = cfg->threshold;
+    if (isnan(threshold)) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;
+    int max_trans = 0, max_res = 0;
+    bssm_pf_noise_shape(cfg->algorithm, T, cfg->obs_times, &max_trans, &max_res);
+    const long long u_stride = (cfg->resample_fn == BSSM_SYSTEMATIC) ? 1 : N;
+    const long long lo = (long long)boff * EB, cnt = (long long)nloc * EB;        // this rank's particles
+    void *d_ess, *d_llh, *d_se, *d_separt, *d_resampled, *d_zi = nullptr, *d_zt = nullptr, *d_ur = nullptr;
+    int rc;
+    if ((rc = pool_get(c, "ess", (size_t)(T + 1) * 8, &d_ess))) return rc;
+    if ((rc = pool_get(c, "llh", (size_t)(T + 1) * 8, &d_llh))) return rc;
+    if ((rc = pool_get(c, "se", (size_t)(T + 1) * 8, &d_se))) return rc;
+    if ((rc = pool_get(c, "separt", (size_t)(T + 1) * B * 8, &d_separt))) return rc;
+    if ((rc = pool_get(c, "resampled", (size_t)(T + 1) * 4, &d_resampled))) return rc;
+    if (cfg->z_init) { if ((rc = pool_get(c, "zi", (size_t)N * 8, &d_zi))) return rc; HIPCHK(hipMemcpyAsync(d_zi, cfg->z_init, (size_t)N * 8, hipMemcpyHostToDevice, c->stream)); }
+    if (cfg->z_trans && max_trans > 0) { if ((rc = pool_get(c, "zt", (size_t)max_trans * N * 8, &d_zt))) return rc; HIPCHK(hipMemcpyAsync(d_zt, cfg->z_trans, (size_t)max_trans * N * 8, hipMemcpyHostToDevice, c->stream)); }
+    if (cfg->u_res && max_res > 0) { if ((rc = pool_get(c, "ur", (size_t)max_res * u_stride * 8, &d_ur))) return rc; HIPCHK(hipMemcpyAsync(d_ur, cfg->u_res, (size_t)max_res * u_stride * 8, hipMemcpyHostToDevice, c->stream)); }
+    HIPCHK(hipMemsetAsync(d_separt, 0, (size_t)(T + 1) * B * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_ess, 0, (size_t)(T + 1) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_llh, 0, (size_t)(T + 1) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_resampled, 0, (size_t)(T + 1) * 4, c->stream));
+    // host staging for the collectives
+    const size_t rec_bytes = (size_t)nloc * sizeof(BlockRec), side_bytes = (size_t)nloc * sizeof(SideList);
+    std::vector<char> hsend(std::max<size_t>({rec_bytes + side_bytes, (size_t)3 * nloc * 8, (size_t)(T + 1) * nloc * 8, (size_t)64})), hrecv(hsend.size() * W);
+    std::vector<double> xsend((size_t)std::min<long long>(N, 2 * cnt + (long long)CAPX)), xrecv((size_t)cnt);
+    auto sync = [&]() -> int { HIPCHK(hipStreamSynchronize(c->stream)); return BSSM_OK; };
+#define SHCHK(expr) do { if ((expr) != 0) { g_err = "bssm_pf_run_sharded: a collective callback failed"; return BSSM_ERR_ARG; } } while (0)
+    // all_gather of one per-block device array slice [boff, boff + nloc) x item bytes, written back to the full device array
+    auto gather_blocks = [&](void* d_arr, size_t item) -> int {
+        HIPCHK(hipMemcpyAsync(hsend.data(), (char*)d_arr + (size_t)boff * item, (size_t)nloc * item, hipMemcpyDeviceToHost, c->stream));
+        if (int r2 = sync()) return r2;
+        SHCHK(sh->all_gather(sh->user, hsend.data(), hrecv.data(), (long long)((size_t)nloc * item)));
+        HIPCHK(hipMemcpyAsync(d_arr, hrecv.data(), (size_t)B * item, hipMemcpyHostToDevice, c->stream));      // rank order == block order
+        return sync();            // (hrecv is reused by the next gather)
+    };
+    ModelPar par; memset(&par, 0, sizeof(par));
+    par.phi = cfg->theta[0]; par.sx = cfg->theta[1]; par.sy = cfg->theta[2]; par.log_sy = log(cfg->theta[2]);
+    const PhiloxKey key = make_key(cfg->seed, cfg->stream);
+    double* X0 = c->x0; double* X1 = c->x1;
+    double* separt = (double*)d_separt;
+    const int lim = c->opt_window > 0 ? c->opt_window : rec_window(N);
+    LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
+    {
+        NoiseSrc ns; ns.arr = (const double*)d_zi; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
+        LAUNCH(c, "k_init", k_init, nloc, NT, 0, X0, N, ns, separt, cfg->model, par, boff);
+    }
+    DevState h; memset(&h, 0, sizeof(h));
+    int ktrans = 0, prev_t = 0;
+    for (int i = 1; i <= T; i++) {                                                        // R/particle_filter_core.R:123
+        const int ot = cfg->obs_times ? cfg->obs_times[i - 1] : i;
+        const int gap = ot - prev_t;
+        prev_t = ot;
+        const double yi = cfg->y[i - 1];
+        auto noise = [&](int k) { NoiseSrc ns; ns.arr = d_zt ? (const double*)d_zt + (size_t)k * N : nullptr; ns.key = key; ns.purpose = DRAW_TRANS; ns.call = (uint32_t)k; return ns; };
+        c->gmax_cur = nullptr;
+        for (int step = 1; step <= gap; step++) {
+            launch_step_model(c, cfg->model, true, (step == gap) ? 1 : 0, false, X0, N, B, par, yi, noise(ktrans));
+            ktrans++;
+        }
+        if (gap <= 0) {
+            NoiseSrc ns = noise(0);
+            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), nloc, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, nullptr, boff);
+            else LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), nloc, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, nullptr, boff);
+        }
+        // (1) the log-sum-exp partials of every block
+        if ((rc = gather_blocks(c->pm, 8)) || (rc = gather_blocks(c->ps, 8)) || (rc = gather_blocks(c->pq, 8))) return rc;
+        double* se_row = separt + (size_t)i * B;
+        FromLw f; f.lw = c->lw; f.w_out = c->w; f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B; f.gmax = nullptr;
+        f.lead = boff; f.pub = boff + nloc / 2; f.ain_out = c->ain_w; f.plan = PLAN_PF; f.N = N; f.obs_i = i;
+        f.resample_algorithm = resample_algorithm; f.threshold = threshold;
+        f.ess_out = (double*)d_ess; f.llh_out = (double*)d_llh; f.resampled_out = (int*)d_resampled;
+        LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), nloc, NT, 0, c->w, N, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr, boff, B);
+        HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        if ((rc = sync())) return rc;
+        if (h.dead || h.flags) break;                                                     // identical on every rank: all leave together
+        if (h.do_resample) {
+            // (2) the records of sum(w), (3) the records of cumsum(w / total): every rank resolves them itself
+            if ((rc = gather_blocks(c->brec, sizeof(BlockRec))) || (rc = gather_blocks(c->side, sizeof(SideList)))) return rc;
+            LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), nloc, NT, 0, c->w, N, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p, boff, B);
+            if ((rc = gather_blocks(c->brec_p, sizeof(BlockRec))) || (rc = gather_blocks(c->side_p, sizeof(SideList)))) return rc;
+            ApplyArgs a;
+            a.w = c->w; a.nw = N; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = (int)N;
+            a.u_base = (const double*)d_ur; a.u_stride = u_stride; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;
+            a.xsrc = X0; a.xdst = X1; a.dim = 1; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = se_row;
+            a.lead = boff; a.last = boff + nloc - 1;
+            a.nstage = c->opt_stage ? 1 : 0;
+            const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), sizeof(ResolveSmem));
+            if (cfg->resample_fn == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), nloc, NT, xshm, a, c->st, c->brec_p, c->side_p, boff, B);
+            else LAUNCH(c, "k_apply<stratified>(+resolve<P>)", (k_apply<0, true>), nloc, NT, xshm, a, c->st, c->brec_p, c->side_p, boff, B);
+            HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            if ((rc = sync())) return rc;
+            // (4) the resampled particles: this rank produced the outputs [out_lo, out_hi); owners are cut at multiples of N / world
+            long long mine[2] = {h.out_lo, h.out_hi};
+            std::vector<long long> all((size_t)2 * W), scnt((size_t)W), rcnt((size_t)W);
+            SHCHK(sh->all_gather(sh->user, mine, all.data(), 16));
+            auto overlap = [](long long a0, long long a1, long long b0, long long b1) { const long long l = std::max(a0, b0), r = std::min(a1, b1); return r > l ? r - l : 0LL; };
+            long long tot_recv = 0;
+            for (int r2 = 0; r2 < W; r2++) {
+                scnt[r2] = overlap(mine[0], mine[1], (long long)r2 * cnt, (long long)(r2 + 1) * cnt);
+                rcnt[r2] = overlap(all[2 * r2], all[2 * r2 + 1], lo, lo + cnt);
+                tot_recv += rcnt[r2];
+            }
+            if (tot_recv != cnt) { g_err = "bssm_pf_run_sharded: the ranks' output ranges do not tile the particles"; return BSSM_ERR_ARG; }
+            const long long nsend = mine[1] - mine[0];
+            if ((long long)xsend.size() < nsend) xsend.resize((size_t)nsend);
+            if (nsend > 0) HIPCHK(hipMemcpyAsync(xsend.data(), X1 + mine[0], (size_t)nsend * 8, hipMemcpyDeviceToHost, c->stream));
+            if ((rc = sync())) return rc;
+            SHCHK(sh->exchange(sh->user, xsend.data(), scnt.data(), xrecv.data(), rcnt.data()));
+            HIPCHK(hipMemcpyAsync(X1 + lo, xrecv.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
+            if ((rc = sync())) return rc;
+        } else {
+            LAUNCH(c, "k_carry", k_carry, nloc, NT, 0, X0, X1, c->w, N, 1, se_row, c->st, boff);
+        }
+        std::swap(X0, X1);
+    }
+#undef SHCHK
+    // state estimates: every rank's per-block partials, then the same reduction kernel as the single-GPU run
+    {
+        HIPCHK(hipMemcpy2DAsync(hsend.data(), (size_t)nloc * 8, separt + boff, (size_t)B * 8, (size_t)nloc * 8, (size_t)(T + 1), hipMemcpyDeviceToHost, c->stream));
+        if ((rc = sync())) return rc;
+        if (sh->all_gather(sh->user, hsend.data(), hrecv.data(), (long long)((size_t)(T + 1) * nloc * 8)) != 0) { g_err = "bssm_pf_run_sharded: a collective callback failed"; return BSSM_ERR_ARG; }
+        std::vector<double> full((size_t)(T + 1) * B);
+        const double* rv = (const double*)hrecv.data();
+        for (int r2 = 0; r2 < W; r2++) for (int i = 0; i <= T; i++)
+            memcpy(&full[(size_t)i * B + (size_t)r2 * nloc], rv + ((size_t)r2 * (T + 1) + i) * nloc, (size_t)nloc * 8);
+        HIPCHK(hipMemcpyAsync(separt, full.data(), full.size() * 8, hipMemcpyHostToDevice, c->stream));
+        LAUNCH(c, "k_reduce_state_est", k_reduce_state_est, T + 1, NT, 0, separt, B, 1, (double*)d_se);
+        if ((rc = sync())) return rc;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(res->state_est, d_se, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(res->ess, d_ess, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (T > 0) HIPCHK(hipMemcpyAsync(res->loglike_history, d_llh, (size_t)T * 8, hipMemcpyDeviceToHost, c->stream));
+    if (res->resampled && T > 0) HIPCHK(hipMemcpyAsync(res->resampled, d_resampled, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    res->ess[0] = 1.0 / (dN * ((1.0 / dN) * (1.0 / dN)));
+    *res->loglike = h.loglike;
+    if (res->early_return_step) *res->early_return_step = h.dead;
+    if (res->n_res_calls) *res->n_res_calls = h.res_calls;
+    if (res->device_ms) *res->device_ms = 0.0;
+    if (h.dead) {
+        for (int i = h.dead; i <= T; i++) { res->ess[i] = 0.0; res->state_est[i] = 0.0; }
+        for (int i = h.dead; i < T; i++) res->loglike_history[i] = 0.0;
+    }
+    if (h.flags) { const int st = flags_to_status(h.flags); if (st != BSSM_ERR_ARG) g_err = bssm_status_string(st); return st; }
     return BSSM_OK;
 }
 

@@ -65,6 +65,7 @@ struct DevState {
     int32_t res_calls;            // resample calls made so far
     int32_t cur_call;             // index of the resample call in flight
     int32_t debug_stop;           // dev tool: kernels return after stage N (0 = run everything)
+    int32_t out_lo, out_hi;       // outputs [out_lo, out_hi) produced by this launch's blocks in the last k_apply (particle-block sharding)
     long long stat_hard_blocks, stat_serial_walks, stat_literal_terms;
     long long stamps[4][16];      // dev tool: clock64() at stage boundaries (debug_stop == 99)
 };
@@ -326,11 +327,12 @@ __device__ __forceinline__ void init_block(double* sh4, const int bidx, double* 
     if (threadIdx.x == 0) { se_part[(long long)bidx * dim] = acc; if (dim > 1) se_part[(long long)bidx * dim + 1] = acc1; }
 }
 
+// (boff: first block of this launch in the global block numbering -- 0 unless one filter's particle blocks are sharded)
 __global__ __launch_bounds__(NT) void k_init(double* __restrict__ x, long long N, NoiseSrc ns,
-                                             double* __restrict__ se_part /* [nblocks][dim] */, int model, ModelPar par)
+                                             double* __restrict__ se_part /* [nblocks][dim] */, int model, ModelPar par, int boff)
 {
     __shared__ double sh4[4];
-    init_block(sh4, (int)blockIdx.x, x, N, ns, se_part, model, par);
+    init_block(sh4, (int)blockIdx.x + boff, x, N, ns, se_part, model, par);
 }
 
 // ---------------------------------------------------------------------------
@@ -349,13 +351,14 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
                                               double* __restrict__ lw, const double* __restrict__ auxg,
                                               long long N, ModelPar par, double y, NoiseSrc ns,
                                               double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq,
-                                              const DevState* __restrict__ st, unsigned long long* __restrict__ gmax)
+                                              const DevState* __restrict__ st, unsigned long long* __restrict__ gmax, int boff)
 {
+    const int bx = (int)blockIdx.x + boff;
     // (no early return on st->dead here: a dependent read of the run state in front of the particle loads would
     //  cost every launch a memory round trip; propagating a dead run is harmless, its results are never read)
     (void)st;
     __shared__ double sh[NTS / 64];
-    const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
+    const long long j = (long long)bx * EB + 2 * (long long)threadIdx.x;
     double l0 = -INFINITY, l1 = -INFINITY;
     if (j < N) {
         const bool two = (j + 1 < N);
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
         q = block_sum_n<NTS / 64>(q, sh);
         // max(log_weights) over the whole grid (R/particle_filter_core.R:204) by one atomic per block: the next kernel reads
         // it with one load instead of reducing the B block maxima again in every workgroup
-        if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; atomicMax(gmax + (blockIdx.x % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
+        if (threadIdx.x == 0) { pm[bx] = bm; ps[bx] = s; pq[bx] = q; if (gmax) atomicMax(gmax + (bx % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
     }
 }
 
@@ -952,6 +955,8 @@ struct PassIn { bool given; double total; double a_in; };
 struct FromLw {
     const double* lw; double* w_out; const double* pm; const double* ps; const double* pq; int nb;
     const unsigned long long* gmax;      // key of max(pm[0..nb)) left by the step kernel's atomics, or nullptr (then reduced here)
+    int lead, pub;                       // the block that records the per-observation scalars (0) / publishes the prefixes (nblk / 2);
+                                         // other values only when a filter's blocks are sharded over ranks (every rank keeps its own run state)
     double* ain_out;
     // per-observation bookkeeping that only needs the partials (R/particle_filter_core.R:189-218): every block
     // derives the same numbers; block 0 records them
@@ -1022,7 +1027,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         }
         const bool degenerate = (f.plan == PLAN_PF) && (M < -1e8);       // all(log_weights < -1e8)  (:189-202)
         if (degenerate) {
-            if (bidx == 0 && t == 0) {
+            if (bidx == f.lead && t == 0) {
                 st->loglike = -INFINITY; f.llh_out[f.obs_i - 1] = -INFINITY; st->dead = f.obs_i; st->do_resample = 0;
             }
             return;
@@ -1054,7 +1059,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         if (f.plan == PLAN_PF) {
             const double ess = 1.0 / (sq / (S * S));                                          // :211
             doit = (f.resample_algorithm == 0) ? 0 : (f.resample_algorithm == 1) ? 1 : (ess < f.threshold);   // :214-218
-            if (bidx == 0 && t == 0) {
+            if (bidx == f.lead && t == 0) {
                 const double ll = st->loglike + (M + log(S) - log((double)f.N));              // :208
                 st->loglike = ll; f.llh_out[f.obs_i - 1] = ll;                                // :209
                 st->do_resample = doit;
@@ -1063,14 +1068,14 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
                 st->ess = ess; st->lse_max = M; st->lse_sum = S;
                 if (doit) { st->cur_call = st->res_calls; st->res_calls += 1; }
             }
-        } else if (bidx == 0 && t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
+        } else if (bidx == f.lead && t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
         if (t == bidx / L) {                      // the one lane whose slice holds this block: one division
             double pp = pre;
 #pragma unroll
             for (int k = 0; k < KMAX; k++) if (k < bidx % L) pp += esv[k];
             sm.bcast = pp / S;
         }
-        if (bidx == nblk / 2) {                   // one (ordinary) block also publishes every block's prefix, for ain_p later;
+        if (bidx == f.pub) {                      // one (ordinary) block also publishes every block's prefix, for ain_p later;
                                                              // not block 0: that one already walks the exact-zero head
             double pp = pre;
 #pragma unroll
@@ -1477,31 +1482,32 @@ template <int MODE, bool FROM_LW, bool INRES = false>
 __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long long nw, const double* __restrict__ ain,
                                               int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
                                               FromLw f, const BlockRec* __restrict__ prev_brec, const SideList* __restrict__ prev_side,
-                                              double* __restrict__ ain_p_out)
+                                              double* __restrict__ ain_p_out, int boff, int nblk_g)
 {
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT];
     __shared__ double es[1];
+    const int bidx = (int)blockIdx.x + boff, nblk = nblk_g ? nblk_g : (int)gridDim.x;
     PassIn pin; pin.given = false; pin.total = 1.0; pin.a_in = 0.0;
     if constexpr (INRES) {
         static_assert(!INRES || (MODE == MODE_P && !FROM_LW), "only the cumsum pass resolves the pass before it");
         __shared__ ResolveSmem rs;
         {
-            const double ain_w = ain[blockIdx.x];
+            const double ain_w = ain[bidx];
             if (st->dead || st->flags || !st->do_resample) return;
-            const uint64_t tb = resolve_in_block<MODE_W>(sm, rs, prev_brec, prev_side, (int)gridDim.x, (int)gridDim.x, w, nw, 1.0, st, blockIdx.x == 0);
+            const uint64_t tb = resolve_in_block<MODE_W>(sm, rs, prev_brec, prev_side, nblk, nblk, w, nw, 1.0, st, bidx == 0);
             const double tot = b2d(tb);
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (bidx == f.lead && threadIdx.x == 0) {
                 st->total_bits = tb;
                 if (tot == 0.0) atomicOr(&st->flags, FLAG_ZERO_SUM);       // src/resampling.cpp:8,22,49
                 if (!isfinite(tot)) atomicOr(&st->flags, FLAG_NONFINITE);
             }
             if (tot == 0.0 || !isfinite(tot)) return;
             pin.given = true; pin.total = tot; pin.a_in = ain_w / tot;
-            if (threadIdx.x == 0) ain_p_out[blockIdx.x] = pin.a_in;
+            if (threadIdx.x == 0) ain_p_out[bidx] = pin.a_in;
         }
     }
-    local_block<MODE, FROM_LW, MAXB>(sm, tin, es, (int)blockIdx.x, (int)gridDim.x, w, nw, ain, lim, brec, side, st, f, pin);
+    local_block<MODE, FROM_LW, MAXB>(sm, tin, es, bidx, nblk, w, nw, ain, lim, brec, side, st, f, pin);
 }
 
 constexpr int NTR = 1024;        // threads of the single resolve workgroup (16 waves)
@@ -1724,6 +1730,7 @@ struct ApplyArgs {
     const double* auxsrc; double* auxdst;                            // gather aux_log_weights[ancestors]
     double* se_part;              // [B][dim] partial sums of x * (1/N) after resampling, or nullptr
     int nstage;                   // k_apply: LDS staging arrays provided by the launch (0..3 x CAPX doubles)
+    int lead, last;               // first / last block of this launch in the global numbering: they record the launch's output range
 };
 
 // Expansion when an element owns more than 64 outputs (degenerate weights: a few particles own almost everything): all
@@ -1855,7 +1862,8 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         for (int k = 0; k < EL; k++) { maxcnt = (Tk[k] - p) > maxcnt ? (Tk[k] - p) : maxcnt; p = Tk[k]; }
     }
     if (maxcnt > 64) sm.big = 1;                                      // (cleared at entry; barriers in between)
-    if (t == 0) Tbegin = tprev;
+    if (t == 0) { Tbegin = tprev; if (bidx == a.lead) st->out_lo = tprev; }
+    if (t == NT - 1 && bidx == a.last) st->out_hi = Tk[EL - 1];
     __syncthreads();
     BSSM_STAMP(st, dbg, 3, 7, stamper);
     const int Tb = Tbegin, Te = Tl[EB - 1];
@@ -1950,8 +1958,9 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
 // k_resolve<P> launch in between.
 template <int KIND, bool INRES = false>
 __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st, const BlockRec* __restrict__ prev_brec,
-                                              const SideList* __restrict__ prev_side)
+                                              const SideList* __restrict__ prev_side, int boff, int nblk_g)
 {
+    const int bidx = (int)blockIdx.x + boff, nblk = nblk_g ? nblk_g : (int)gridDim.x;
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT];
     __shared__ int Tl[EB];
@@ -1963,12 +1972,11 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st, const B
         // (the resolve's scratch lives in the staging area, which is not in use yet: the launch sizes the dynamic LDS for both)
         ResolveSmem& rs = *reinterpret_cast<ResolveSmem*>(lx);
         if (st->dead || !st->do_resample || st->flags) return;
-        cin_val = resolve_in_block<MODE_P>(sm, rs, prev_brec, prev_side, (int)gridDim.x, (int)blockIdx.x, a.w, a.nw, b2d(st->total_bits), st,
-                                           blockIdx.x == gridDim.x - 1);
+        cin_val = resolve_in_block<MODE_P>(sm, rs, prev_brec, prev_side, nblk, bidx, a.w, a.nw, b2d(st->total_bits), st, bidx == nblk - 1);
         has_cin = true;
         __syncthreads();                                             // the staging area is free again
     }
-    apply_block<KIND>(sm, tin, Tl, Tbegin, (int)blockIdx.x, (int)gridDim.x, a, st, a.nstage ? lx : nullptr, a.nstage, has_cin, cin_val);
+    apply_block<KIND>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage, has_cin, cin_val);
 }
 
 // multinomial: inverse CDF on the exact cum_sum (distributional parity only)
@@ -2215,10 +2223,10 @@ __device__ __forceinline__ void carry_block(double* sh4, const int bidx, const d
 
 __global__ __launch_bounds__(NT) void k_carry(const double* __restrict__ xsrc, double* __restrict__ xdst,
                                               const double* __restrict__ w, long long N, int dim,
-                                              double* __restrict__ se_part, const DevState* __restrict__ st)
+                                              double* __restrict__ se_part, const DevState* __restrict__ st, int boff)
 {
     __shared__ double sh4[4];
-    carry_block(sh4, (int)blockIdx.x, xsrc, xdst, w, N, dim, se_part, st);
+    carry_block(sh4, (int)blockIdx.x + boff, xsrc, xdst, w, N, dim, se_part, st);
 }
 
 // state_est[i] = sum over blocks of the partials written for observation i
@@ -2468,7 +2476,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             step_emul<MODEL, false, 2>(sh16, xa, AUXLW, nullptr, N, par, yi, ns, &pm1, &ps1, &pq1);
             __syncthreads();
             FromLw fa;
-            fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.gmax = nullptr; fa.ain_out = &ainw1;
+            fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.gmax = nullptr; fa.lead = 0; fa.pub = 0; fa.ain_out = &ainw1;
             fa.plan = PLAN_AUX; fa.N = N; fa.obs_i = i; fa.resample_algorithm = g.resample_algorithm; fa.threshold = g.threshold;
             fa.ess_out = nullptr; fa.llh_out = nullptr; fa.resampled_out = nullptr;
             if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa);
@@ -2486,7 +2494,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             ApplyArgs aa;
             aa.w = LW; aa.nw = N; aa.ain_p = &ainp1; aa.cin = &cin1; aa.lim = g.lim; aa.n = (int)N;
             aa.u_base = nullptr; aa.u_stride = 0; aa.key = key; aa.anc_out = nullptr; aa.anc_stride = 0; aa.cum_out = nullptr;
-            aa.xsrc = xa; aa.xdst = xb; aa.dim = D; aa.xstride = N; aa.auxsrc = AUXLW; aa.auxdst = AUXG; aa.se_part = nullptr; aa.nstage = 0;
+            aa.xsrc = xa; aa.xdst = xb; aa.dim = D; aa.xstride = N; aa.auxsrc = AUXLW; aa.auxdst = AUXG; aa.se_part = nullptr; aa.nstage = 0; aa.lead = 0; aa.last = 0;
             if (g.resample_fn == 1) {
                 if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, aa, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, aa, &st);
             } else if (g.resample_fn == 0) {
@@ -2511,7 +2519,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         }
         if (t == 0) { sep[0] = 0.0; sep[1] = 0.0; }
         FromLw fl;
-        fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.gmax = nullptr; fl.ain_out = &ainw1;
+        fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.gmax = nullptr; fl.lead = 0; fl.pub = 0; fl.ain_out = &ainw1;
         fl.plan = PLAN_PF; fl.N = N; fl.obs_i = i; fl.resample_algorithm = g.resample_algorithm; fl.threshold = g.threshold;
         fl.ess_out = g.ess + (long long)fi * (T + 1); fl.llh_out = g.llh + (long long)fi * T; fl.resampled_out = nullptr;
         // normalise + loglik/ESS/decision + the exact sum(weights) of the block (:204-218, src/resampling.cpp:20-24)
@@ -2531,7 +2539,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         ApplyArgs a;
         a.w = LW; a.nw = N; a.ain_p = &ainp1; a.cin = &cin1; a.lim = g.lim; a.n = (int)N;
         a.u_base = nullptr; a.u_stride = 0; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;
-        a.xsrc = xa; a.xdst = xb; a.dim = D; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = sep; a.nstage = 0;
+        a.xsrc = xa; a.xdst = xb; a.dim = D; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = sep; a.nstage = 0; a.lead = 0; a.last = 0;
         if (g.resample_fn == 1) {                                                         // systematic
             if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
         } else if (g.resample_fn == 0) {                                                  // stratified
@@ -2567,6 +2575,7 @@ __global__ void k_reset_state(DevState* st)
 {
     st->loglike = 0.0; st->lse_max = 0.0; st->lse_sum = 0.0; st->ess = 0.0; st->total_bits = 0;
     st->do_resample = 0; st->dead = 0; st->flags = 0; st->res_calls = 0; st->cur_call = 0; st->debug_stop = 0;
+    st->out_lo = 0; st->out_hi = 0;
     st->stat_hard_blocks = 0; st->stat_serial_walks = 0; st->stat_literal_terms = 0;
 }
 

@@ -181,6 +181,26 @@ typedef struct {
 
 int bssm_pf_run(bssm_ctx* ctx, const bssm_pf_config* cfg, bssm_pf_result* res);
 
+/* ---- one filter, particle blocks sharded over ranks (prototype) ----
+ * Rank r of `world` holds the particles [r N / world, (r + 1) N / world) = a contiguous run of scan blocks of the GLOBAL
+ * block numbering and runs the same kernels on them; per observation the ranks exchange
+ *   (1) the per-block log-sum-exp partials         (all_gather, 24 B a block)       R/particle_filter_core.R:204-207
+ *   (2) the block records of sum(w)                (all_gather)                      src/resampling.cpp:20
+ *   (3) the block records of cumsum(w / total)     (all_gather)                      src/resampling.cpp:24-25
+ *   (4) the resampled particles                    (all-to-all: every rank's outputs are one contiguous range) R/resampling.R:40
+ * and every rank resolves the exact sums redundantly, so the result is bit-identical to bssm_pf_run on one GPU.
+ * The collectives are the caller's (host-staged callbacks: torch.distributed / RCCL / MPI); they return 0 on success.
+ * Limits of the prototype: bootstrap filter, scalar-state Gaussian models, stratified / systematic resampling,
+ * N a multiple of world x 2048 and at most 2^20, no histories.  Every rank returns the full result. */
+typedef struct {
+    int rank, world;
+    int (*all_gather)(void* user, const void* send, void* recv, long long bytes_per_rank);       /* recv holds world x bytes_per_rank */
+    int (*exchange)(void* user, const double* send, const long long* send_counts /* [world] */,
+                    double* recv, const long long* recv_counts /* [world] */);                    /* all-to-all of doubles, pieces in rank order */
+    void* user;
+} bssm_shard;
+int bssm_pf_run_sharded(bssm_ctx* ctx, const bssm_pf_config* cfg, const bssm_shard* shard, bssm_pf_result* res);
+
 /* ---- many small filters per launch ----------------------------------------
  * The reference runs its filters at N <= 1000 inside PMMH (R/pmmh.R:403-415,445-457) and 100 of them at N = 100 in the
  * pilot (R/pmmh_tuning.R:111-151): launch-bound one at a time.  bssm_pf_run_batch runs n_filters independent bootstrap
