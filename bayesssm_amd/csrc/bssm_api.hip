@@ -203,6 +203,7 @@ extern "C" int bssm_ctx_set_option(bssm_ctx* c, int option, int value)
     return BSSM_OK;
 }
 __global__ void k_set_debug(DevState* st, int v) { st->debug_stop = v; }
+__global__ void k_set_calls(DevState* st, int v) { st->res_calls = v; }       // the next resample call draws the generator's stream `v`
 extern "C" int bssm_ctx_get_stamps(bssm_ctx* c, long long* out /* [4][16] */)
 {   // DEV builds (make DEV=1): the clock64() stage stamps of the last run; zeros otherwise
     if (!c || !out) ARGFAIL("bssm_ctx_get_stamps: NULL argument");
@@ -723,6 +724,63 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         const int rows = h.dead ? h.dead : T + 1;
         HIPCHK(hipMemcpy(res->particles_history, d_ph, (size_t)rows * N * dim * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(res->weights_history, d_wh, (size_t)rows * N * 8, hipMemcpyDeviceToHost));
+    }
+    return BSSM_OK;
+}
+
+// ---- closure mode: normalise, decide, resample for host-evaluated log-weights -------------------------------------
+extern "C" int bssm_pf_weigh_resample(bssm_ctx* c, long long n, const double* lw, int always, int resample_algorithm,
+                                      double threshold, int resample_fn, const double* U, unsigned long long seed,
+                                      unsigned long long stream, int call, double* weights_out, int* ancestors_out,
+                                      double* scalars_out, int* flags_out)
+{
+    if (!c || !lw || !scalars_out || !flags_out) ARGFAIL("bssm_pf_weigh_resample: NULL argument");
+    if (n <= 0) ARGFAIL("num_particles must be a positive count");
+    if (n > c->cap) { g_err = "bssm_pf_weigh_resample: num_particles exceeds context capacity"; return BSSM_ERR_CAPACITY; }
+    if (resample_algorithm < 0 || resample_algorithm > 2) ARGFAIL("bssm_pf_weigh_resample: unknown resample_algorithm");
+    if (resample_fn < 0 || resample_fn > 3) ARGFAIL("bssm_pf_weigh_resample: unknown resample_fn");
+    if (resample_fn == BSSM_MULTINOMIAL_R && !U) ARGFAIL("bssm_pf_weigh_resample: BSSM_MULTINOMIAL_R replays R's unif_rand() stream: U is required");
+    if (call < 0) ARGFAIL("bssm_pf_weigh_resample: call must be >= 0");
+    HIPCHK(hipSetDevice(c->device));
+    const int B = (int)((n + EB - 1) / EB);
+    const double dN = (double)n;
+    if (isnan(threshold)) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;
+    const long long nu = (resample_fn == BSSM_SYSTEMATIC) ? 1 : n;
+    void *d_small, *d_anc, *d_u = nullptr;
+    int rc;
+    if ((rc = pool_get(c, "wr_small", 64, &d_small))) return rc;          // ess_out[2], llh_out[1], resampled[1]
+    if ((rc = pool_get(c, "wr_anc", (size_t)n * 4, &d_anc))) return rc;
+    HIPCHK(hipMemcpyAsync(c->lw, lw, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if (U) { if ((rc = pool_get(c, "wr_u", (size_t)nu * 8, &d_u))) return rc; HIPCHK(hipMemcpyAsync(d_u, U, (size_t)nu * 8, hipMemcpyHostToDevice, c->stream)); }
+    HIPCHK(hipMemsetAsync(d_small, 0, 64, c->stream));
+    LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
+    LAUNCH(c, "k_lw_partials", k_lw_partials, B, NTS, 0, c->lw, n, c->pm, c->ps, c->pq);
+    c->gmax_cur = nullptr;
+    ResampleLaunch r;
+    r.d_lw = c->lw; r.plan = always ? PLAN_AUX : PLAN_PF; r.check_degenerate = always ? 0 : 1; r.obs_i = 1;
+    r.resample_algorithm = resample_algorithm; r.threshold = threshold;
+    r.d_ess = (double*)d_small; r.d_llh = (double*)d_small + 2; r.d_resampled = (int*)((double*)d_small + 4);
+    r.d_w = c->w; r.nw = n; r.n = (int)n; r.kind = resample_fn;
+    // the generator's resample draws are indexed by call: place the injected draws so that call 0 reads them
+    r.d_u = (const double*)d_u; r.u_stride = 0; r.key = make_key(seed, stream);
+    r.d_anc = (int*)d_anc; r.anc_stride = 0; r.d_cum = nullptr;
+    r.xsrc = nullptr; r.xdst = nullptr; r.dim = 1; r.xstride = 0; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = nullptr;
+    if (!U && call > 0) hipLaunchKernelGGL(k_set_calls, dim3(1), dim3(1), 0, c->stream, c->st, call);
+    launch_scan_and_apply(c, r);
+    HIPCHK(hipGetLastError());
+    DevState h;
+    HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    flags_out[0] = 0; flags_out[1] = h.dead ? 1 : 0;
+    scalars_out[0] = h.loglike; scalars_out[1] = h.ess; scalars_out[2] = h.lse_max; scalars_out[3] = h.lse_sum;
+    if (h.dead) return BSSM_OK;
+    if (h.flags) { const int st = flags_to_status(h.flags); if (st != BSSM_ERR_ARG) g_err = bssm_status_string(st); return st; }
+    if (weights_out) HIPCHK(hipMemcpy(weights_out, c->w, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (h.do_resample) {
+        if (!ancestors_out) ARGFAIL("bssm_pf_weigh_resample: ancestors_out is required when the observation resamples");
+        HIPCHK(hipMemcpy(ancestors_out, d_anc, (size_t)n * 4, hipMemcpyDeviceToHost));
+        flags_out[0] = 1;
     }
     return BSSM_OK;
 }

@@ -402,6 +402,27 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
     }
 }
 
+// k_lw_partials: the per-block (max, sum exp, sum exp^2) partials of k_step for log-weights that are ALREADY in HBM --
+// closure mode: the model's log_likelihood_fn ran on the host (R/particle_filter_core.R:177-183), the normalisation,
+// log-likelihood, ESS, resample decision and resampling (:204-224) run here.  Same block shape and reduction order as k_step.
+__global__ __launch_bounds__(NTS) void k_lw_partials(const double* __restrict__ lw, long long N, double* __restrict__ pm,
+                                                     double* __restrict__ ps, double* __restrict__ pq)
+{
+    __shared__ double sh[NTS / 64];
+    const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
+    double l0 = -INFINITY, l1 = -INFINITY;
+    if (j < N) { l0 = lw[j]; if (j + 1 < N) l1 = lw[j + 1]; }
+    const double bm = block_max_n<NTS / 64>(fmax(l0, l1), sh);
+    double s = 0.0, q = 0.0;
+    if (bm > -INFINITY) {
+        if (l0 > -INFINITY) { const double e = exp(l0 - bm); s += e; q += e * e; }
+        if (l1 > -INFINITY) { const double e = exp(l1 - bm); s += e; q += e * e; }
+    }
+    s = block_sum_n<NTS / 64>(s, sh);
+    q = block_sum_n<NTS / 64>(q, sh);
+    if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; }
+}
+
 // SIR variant of k_step (state dimension 2, data-dependent Gillespie loop: VALU/divergence-bound, not HBM-bound)
 template <bool TRANS, int WEIGHT, bool SUBAUX>
 __global__ __launch_bounds__(NTS) void k_step_sir(const double* xin, double* xout /* may alias xin */,

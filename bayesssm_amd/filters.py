@@ -191,6 +191,12 @@ def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
     build: seed, stream, draws, ctx, return_ancestors."""
     resample_algorithm = _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")
     resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    from .closures import is_closure_model, particle_filter_closures
+    if is_closure_model(init_fn, transition_fn, log_likelihood_fn):
+        # plain callables: the model runs on the host, the core's own work on the device (closures.py)
+        extra = {k: kwargs.pop(k) for k in ("ctx", "u_res") if k in kwargs}
+        return particle_filter_closures(y, num_particles, init_fn, transition_fn, log_likelihood_fn, None, None, obs_times, "BPF",
+                                        resample_algorithm, resample_fn, threshold, return_particles, **extra, **kwargs)
     r_seed = kwargs.pop("r_seed", None)
     ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
     model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
@@ -239,6 +245,12 @@ def auxiliary_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
     """auxiliary_filter (R/auxiliary_filter.R:163-216)."""
     resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
     resample_algorithm = _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")
+    from .closures import is_closure_model, particle_filter_closures
+    if is_closure_model(init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn):
+        extra = {k: kwargs.pop(k) for k in ("ctx", "u_res") if k in kwargs}
+        return particle_filter_closures(y, num_particles, init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn, None,
+                                        obs_times, "APF", resample_algorithm, resample_fn, threshold, return_particles,
+                                        **extra, **kwargs)
     ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
     model = models.resolve(init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn)
     theta = models.theta_from_kwargs((init_fn, transition_fn, log_likelihood_fn, aux_log_likelihood_fn), kwargs)
@@ -253,6 +265,11 @@ def resample_move_filter(y, num_particles, init_fn, transition_fn, log_likelihoo
     reference's own example; arbitrary R closures cannot run on the device."""
     resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
     kwargs.pop("resample_algorithm", None)                    # removed from ... by the reference too (:213-216)
+    from .closures import is_closure_model, particle_filter_closures
+    if is_closure_model(init_fn, transition_fn, log_likelihood_fn, move_fn):
+        extra = {k: kwargs.pop(k) for k in ("ctx", "u_res") if k in kwargs}
+        return particle_filter_closures(y, num_particles, init_fn, transition_fn, log_likelihood_fn, None, move_fn, obs_times,
+                                        "RMPF", "SISR", resample_fn, None, return_particles, **extra, **kwargs)
     ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
     if not isinstance(move_fn, models.MoveFn):
         raise TypeError("move_fn must be a built-in move descriptor (model.rw_move_fn(sd))")

@@ -355,6 +355,171 @@ def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, prop
     return outs
 
 
+def _mvrnorm(mu, sigma, z):
+    """MASS::mvrnorm(1, mu, Sigma) on p standard normals z (R/pmmh.R:425-428): mu + V diag(sqrt(pmax(ev, 0))) z with
+    eigen(Sigma, symmetric = TRUE) (eigenvalues decreasing, each eigenvector's largest component positive)."""
+    ev, vec = np.linalg.eigh(np.asarray(sigma, dtype=np.float64))
+    ev, vec = ev[::-1], vec[:, ::-1]
+    if not np.all(ev >= -1e-6 * abs(ev[0])):
+        raise ValueError("'Sigma' is not positive definite")
+    big = np.abs(vec).argmax(axis=0)
+    vec = vec * np.where(vec[big, np.arange(len(ev))] < 0, -1.0, 1.0)
+    return np.asarray(mu) + (vec * np.sqrt(np.maximum(ev, 0.0))) @ np.asarray(z)
+
+
+def run_chain_host(pf, m, init_theta, proposal_cov, transform, priors, rng, return_latent_state_est=False):
+    """chain_result's loop (R/pmmh.R:403-415,422-500) on the host, for models given as closures: `pf(theta)` runs one
+    filter (closure mode: the model on the host, the core's work on the device) and returns its result list; `priors` are
+    callables; proposal / acceptance draws come from `rng`."""
+    p = len(priors)
+    cur = np.array(init_theta, dtype=np.float64)
+    scale = np.array([1 / cur[j] if transform[j] == "log" else 1 / (cur[j] * (1 - cur[j])) if transform[j] == "logit" else 1.0
+                      for j in range(p)])
+    cov_trans = np.diag(scale) @ np.asarray(proposal_cov, dtype=np.float64).reshape(p, p) @ np.diag(scale)     # :378-389
+    theta_chain = np.empty((m, p))
+    se_chain = [None] * m
+    r0 = pf(cur)                                                                                               # :403-417
+    cur_ll, cur_se = r0["loglike"], r0["state_est"]
+    theta_chain[0], se_chain[0] = cur, cur_se
+    accepted = 0
+    for i in range(1, m):                                                                                      # :422
+        prop = _back_transform(_mvrnorm(_transform(cur, transform), cov_trans, rng.standard_normal(p)), transform)   # :424-432
+        lp_prop = np.array([pr(v) for pr, v in zip(priors, prop)])
+        if not np.all(np.isfinite(lp_prop)):                                                                   # :435-442
+            theta_chain[i], se_chain[i] = cur, cur_se
+            continue
+        rp = pf(prop)                                                                                          # :445-458
+        lp_cur = np.array([pr(v) for pr, v in zip(priors, cur)])
+        lar = (rp["loglike"] + lp_prop.sum() + _log_jacobian(prop, transform)) - \
+              (cur_ll + lp_cur.sum() + _log_jacobian(cur, transform))                                          # :461-485
+        if np.isnan(lar):
+            lar = -np.inf                                                                                      # :488-490
+        if np.log(rng.random()) < lar:                                                                         # :492-496
+            cur, cur_ll, cur_se = prop, rp["loglike"], rp["state_est"]
+            accepted += 1
+        theta_chain[i], se_chain[i] = cur, cur_se
+    return {"theta_chain": theta_chain, "state_est_chain": np.array(se_chain) if return_latent_state_est else None,
+            "accepted": accepted, "device_ms": 0.0}
+
+
+def _closure_formals(fn):
+    import inspect
+    return [n for n, q in inspect.signature(fn).parameters.items() if q.kind not in (q.VAR_KEYWORD, q.VAR_POSITIONAL)]
+
+
+def _pmmh_closures(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors, pilot_init_params, burn_in,
+                   num_chains, obs_times, resample_algorithm, resample_fn, param_transform, tune_control, verbose,
+                   return_latent_state_est, seed, kwargs):
+    """pmmh (R/pmmh.R:243-630) for models given as closures: the pilot (R/pmmh_tuning.R:111-317) and the chain loop run on
+    the host, every filter through closure mode (closures.py)."""
+    from .resampling import set_seed
+    tune_control = dict(tune_control or default_tune_control())
+    y = np.asarray(y, dtype=np.float64)
+    if not np.all(np.isfinite(y)):
+        raise ValueError("Assertion on 'y' failed: Contains missing values")
+    if not (isinstance(m, (int, np.integer)) and m >= 1):
+        raise ValueError("Assertion on 'm' failed: Must be >= 1")
+    if not (isinstance(burn_in, (int, np.integer)) and 0 <= burn_in <= m - 1):
+        raise ValueError("Assertion on 'burn_in' failed")
+    if not (isinstance(pilot_init_params, (list, tuple)) and len(pilot_init_params) == num_chains):
+        raise ValueError("Assertion on 'pilot_init_params' failed: Must have length %d" % num_chains)
+    names0 = list(pilot_init_params[0].keys())
+    if any(list(q.keys()) != names0 for q in pilot_init_params):
+        raise ValueError("Assertion on 'pilot_init_params' failed: Must be TRUE")
+    if not names0:
+        raise ValueError("pilot_init_params must contain at least one parameter.")
+    fn_params = []                                                   # .check_params_match (R/utils.R:15-72)
+    for fn in (init_fn, transition_fn, log_likelihood_fn):
+        for a in _closure_formals(fn):
+            if a not in ("num_particles", "particles", "y", "t") and a not in fn_params:
+                fn_params.append(a)
+    if not all(q in names0 for q in fn_params):
+        raise ValueError("Parameters in functions do not match the names in pilot_init_params")
+    if not all(q in log_priors for q in fn_params):
+        raise ValueError("Parameters in functions do not match the names in log_priors")
+    _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")       # validated, not forwarded (:287-288)
+    _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    prior_names = list(log_priors.keys())
+    if param_transform is None:
+        param_transform = {k: "identity" for k in prior_names}
+    elif not isinstance(param_transform, dict):
+        raise ValueError("param_transform must be a list.")
+    elif not all(k in param_transform for k in prior_names):
+        raise ValueError("param_transform must include an entry for every parameter in log_priors.")
+    else:
+        bad = [k for k, v in param_transform.items() if v not in ("log", "logit", "identity")]
+        if bad:
+            warnings.warn("Only 'log', 'logit', and 'identity' transformations are supported. Using 'identity' for invalid entries.")
+            param_transform = dict(param_transform, **{k: "identity" for k in bad})
+    transform = [param_transform[k] for k in prior_names]
+    priors = [log_priors[k] for k in prior_names]
+    if seed is None:
+        seed = int(np.random.default_rng().integers(1, 2 ** 31 - 1))
+    seeds = np.random.default_rng(seed).integers(1, 2 ** 31 - 1, size=num_chains)            # R/pmmh.R:511
+    print_result = bool(kwargs.pop("print_result", True))
+    ctx = kwargs.pop("ctx", None)
+    dist = None
+    try:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            dist = tdist
+    except Exception:
+        dist = None
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    mine = chain_assignment(num_chains, world)[rank]
+    extra = dict(kwargs)
+    if ctx is not None:
+        extra["ctx"] = ctx
+
+    def run_pf(theta, n, **over):
+        return pf_wrapper(y, int(n), init_fn, transition_fn, log_likelihood_fn, obs_times=obs_times, return_particles=False,
+                          **over, **dict(zip(prior_names, [float(v) for v in theta])), **extra)
+
+    local, extras_out = {}, {}
+    for c in mine:                                                    # chain_result (:345-505)
+        set_seed(int(seeds[c]))                                       # set.seed(seed) (:346): the resampling stream of this chain
+        rng = np.random.default_rng([int(seeds[c]), 77])
+        if verbose:
+            print("Running chain %d..." % (c + 1)); print("Running pilot chain for tuning...")
+        pilot = run_pilot_chain(
+            lambda th, n, tag: run_pf(th, n, resample_algorithm=tune_control["pilot_resample_algorithm"],
+                                      resample_fn=tune_control["pilot_resample_fn"])["loglike"],
+            tune_control["pilot_m"], tune_control["pilot_n"], tune_control["pilot_reps"], priors,
+            tune_control["pilot_proposal_sd"], transform, [float(pilot_init_params[c][k]) for k in prior_names], rng, verbose,
+            message=(print if verbose else (lambda *_: None)))
+        if verbose:
+            print("Running Particle MCMC chain with tuned settings...")
+        out = run_chain_host(lambda th: run_pf(th, pilot["target_n"]), m, pilot["pilot_theta_mean"], pilot["pilot_theta_cov"],
+                             transform, priors, rng, return_latent_state_est)
+        out["pilot"] = pilot
+        local[c], extras_out[c] = out["theta_chain"], out
+    n_params = len(prior_names)
+    chains = gather_chains(local, num_chains, m, n_params, dist)
+    post = chains[:, burn_in:, :]
+    diag_ess, diag_rhat = {}, {}
+    for j, name in enumerate(prior_names):
+        mat = np.ascontiguousarray(post[:, :, j].T)
+        diag_ess[name] = diagnostics.ess(mat) if num_chains > 1 else float("nan")
+        diag_rhat[name] = diagnostics.rhat(mat)
+    result = diagnostics.PmmhOutput({
+        "theta_chain": {"chain": np.repeat(np.arange(1, num_chains + 1), m - burn_in),
+                        **{name: post[:, :, j].reshape(-1) for j, name in enumerate(prior_names)}},
+        "diagnostics": {"ess": diag_ess, "rhat": diag_rhat},
+        "_extras": {"local_chains": extras_out, "seeds": seeds, "rank": rank, "world_size": world},
+    })
+    if return_latent_state_est:
+        result["latent_state_chain"] = {c: extras_out[c]["state_est_chain"][burn_in:] for c in mine}
+    if rank == 0 and print_result:
+        print(result.format())
+    if any(np.isfinite(v) and v < 400 for v in diag_ess.values()):
+        warnings.warn("Some ESS values are below 400, indicating poor mixing. Consider running the chains for more iterations.")
+    if any(np.isfinite(v) and v > 1.01 for v in diag_rhat.values()):
+        warnings.warn("\nSome Rhat values are above 1.01, indicating that the chains have not converged. \n"
+                      "Consider running the chains for more iterations and/or increase burn_in.")
+    return result
+
+
 def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors, pilot_init_params, burn_in,
          num_chains=4, obs_times=None, resample_algorithm=None, resample_fn=None, param_transform=None,
          tune_control=None, verbose=False, return_latent_state_est=False, seed=None, num_cores=1,
@@ -375,6 +540,15 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     filters run up to `chains_per_gpu` chains concurrently on separate HIP streams.  Either way a chain's draws are keyed
     by (seed, chain index): results do not depend on the placement (tests/testthat/test-pmmh.R:499-503).
     """
+    if not (isinstance(num_chains, (int, np.integer)) and num_chains >= 1):
+        raise ValueError("Assertion on 'num_chains' failed: Must be >= 1")
+    from .closures import is_closure_model
+    if is_closure_model(init_fn, transition_fn, log_likelihood_fn):
+        if num_particles is not None or proposal_cov is not None:
+            raise ValueError("num_particles / proposal_cov overrides belong to the built-in device models")
+        return _pmmh_closures(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors, pilot_init_params,
+                              burn_in, num_chains, obs_times, resample_algorithm, resample_fn, param_transform, tune_control,
+                              verbose, return_latent_state_est, seed, kwargs)
     tune_control = tune_control or default_tune_control()
     y = np.asarray(y, dtype=np.float64)
     if not np.all(np.isfinite(y)):
@@ -383,8 +557,6 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
         raise ValueError("Assertion on 'm' failed: Must be >= 1")
     if not (isinstance(burn_in, (int, np.integer)) and 0 <= burn_in <= m - 1):
         raise ValueError("Assertion on 'burn_in' failed")
-    if not (isinstance(num_chains, (int, np.integer)) and num_chains >= 1):
-        raise ValueError("Assertion on 'num_chains' failed: Must be >= 1")
     if not (isinstance(pilot_init_params, (list, tuple)) and len(pilot_init_params) == num_chains):
         raise ValueError("Assertion on 'pilot_init_params' failed: Must have length %d" % num_chains)
     names0 = list(pilot_init_params[0].keys())

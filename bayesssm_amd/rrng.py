@@ -61,6 +61,12 @@ class RRandom:
         self.buf = np.where(1.0 - x <= 0.0, 1.0 - 0.5 * _I2_32M1, x)
         self.mti = 0
 
+    def snapshot(self):
+        return (self.mt.copy(), self.mti, None if self.buf is None else self.buf.copy())
+
+    def restore(self, snap):
+        self.mt, self.mti, self.buf = snap[0].copy(), snap[1], None if snap[2] is None else snap[2].copy()
+
     def unif_rand(self):
         if self.mti >= _N:
             self._refill()

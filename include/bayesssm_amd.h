@@ -181,6 +181,23 @@ typedef struct {
 
 int bssm_pf_run(bssm_ctx* ctx, const bssm_pf_config* cfg, bssm_pf_result* res);
 
+/* ---- closure mode: the device half of one observation for ARBITRARY models -------------------------------------
+ * The reference's models are user closures (init_fn / transition_fn / log_likelihood_fn, R/particle_filter-doc.R:7-35);
+ * closures cannot run on the GPU, so for models that are not built in the host evaluates them (any state dimension,
+ * y a T x p matrix, t-dependent) and hands the device the N log-weights of the observation; the device does what
+ * .particle_filter_core does with them (R/particle_filter_core.R:189-224):
+ *   all(lw < -1e8) guard; max / exp / sum normalisation -> weights; log-likelihood increment max + log(sum) - log(N);
+ *   ESS = 1 / sum(w^2); resample decision (SIS / SISR / SISAR vs threshold; `always` = the APF's first stage and the
+ *   resample-move filter); resample_*_cpp -> 1-based ancestor indices (the host gathers particles[indices, ], as
+ *   R/resampling.R:20,40,60 does).
+ * lw: N host doubles.  U: the resampler's draws (1 for systematic, N otherwise) or NULL => generator (seed, stream, call).
+ * weights_out (N, optional), ancestors_out (N, required when a resample can happen), scalars[4] = {log-likelihood
+ * increment, ESS, max, sum}; flags_out[2] = {resampled, degenerate (all log-weights < -1e8: the caller returns -Inf)}. */
+int bssm_pf_weigh_resample(bssm_ctx* ctx, long long n, const double* log_weights, int always, int resample_algorithm,
+                           double threshold, int resample_fn, const double* U, unsigned long long seed,
+                           unsigned long long stream, int call, double* weights_out, int* ancestors_out,
+                           double* scalars_out, int* flags_out);
+
 /* ---- one filter, particle blocks sharded over ranks (prototype) ----
  * Rank r of `world` holds the particles [r N / world, (r + 1) N / world) = a contiguous run of scan blocks of the GLOBAL
  * block numbering and runs the same kernels on them; per observation the ranks exchange
