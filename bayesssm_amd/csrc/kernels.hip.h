@@ -760,6 +760,45 @@ __device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, boo
     return exc;
 }
 
+// The same scan for the grid-level resolve, where a lane may hold non-PURE blocks WITH a PURE run behind them: a boundary
+// lane contributes `val` = the run behind its last non-PURE block (its "tail") and restarts the segment at itself; `nent` is
+// the number of its non-PURE blocks.  Returns the PURE composite between the previous boundary lane (tail included) and this
+// lane, the number of non-PURE blocks in front of the lane (ent_before) and in the whole workgroup (ent_total).
+template <int NW>
+__device__ __forceinline__ Pure seg_excl_scan_tail(SegSmem& sm, const Pure& val, bool isb, int nent, int& ent_before, int& ent_total)
+{
+    static_assert(NW <= 4, "workgroups of up to four waves");
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned long long bal = __ballot(isb);
+    Pure v = val;
+    int fi = isb ? 1 : 0, cn = nent;
+#define STEP(C, R) { Pure pv; pv.d0 = dpp_i64<C, R>(0, v.d0); pv.d1 = dpp_i64<C, R>(0, v.d1); const int pf = dpp_i32<C, R>(0, fi); \
+                     cn += dpp_i32<C, R>(0, cn); if (!fi) { v = pure_compose(pv, v); fi = pf; } }
+    BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
+    // v = composite from the last boundary lane at or below this lane (its tail included), or from the wave start
+    if (lane == 63) { sm.wagg[wave] = v; sm.wflag[wave] = (bal != 0ull) ? 1 : 0; sm.wnb[wave] = cn; }
+    __syncthreads();
+    Pure carry; carry.d0 = 0; carry.d1 = 0;
+    int before = 0, all_n = 0;
+    {
+        Pure all; all.d0 = 0; all.d1 = 0;
+#pragma unroll
+        for (int wv = 0; wv < NW; wv++) {
+            if (wv == wave) { carry = all; before = all_n; }
+            if (sm.wflag[wv]) all = sm.wagg[wv]; else all = pure_compose(all, sm.wagg[wv]);
+            all_n += sm.wnb[wv];
+        }
+    }
+    ent_total = all_n;
+    // lanes with no boundary at or below them still belong to the segment carried in from the waves before
+    const bool carried = (bal & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))) == 0ull;
+    const Pure inc = carried ? pure_compose(carry, v) : v;
+    Pure exc; exc.d0 = dpp_i64<DPP_WAVE_SHR1, 0xf>(carry.d0, inc.d0); exc.d1 = dpp_i64<DPP_WAVE_SHR1, 0xf>(carry.d1, inc.d1);
+    ent_before = before + (cn - nent);
+    return exc;
+}
+
 template <int MODE>
 __device__ __forceinline__ void load_terms(const double* __restrict__ w, long long nw, double total, long long j0, double (&v)[EL])
 {
@@ -970,8 +1009,9 @@ __device__ __forceinline__ Rec pure_to_rec(const Pure& p, uint64_t base, long lo
 // FROM_LW (filter path, MODE_W): the kernel also IS the normalisation step -- it turns log-weights
 // into weights  w = exp(lw - max) / sum  (R/particle_filter_core.R:205-207), writes them, and derives
 // the approximate block prefixes from the log-sum-exp partials instead of a separate pass.
-// what a pass takes over from the pass before it when the consuming workgroup resolved that pass itself (resolve_in_block)
-struct PassIn { bool given; double total; double a_in; };
+// The grid-level resolve of the pass BEFORE a kernel, run inside that kernel right after its own loads have been issued
+// (their latency then hides under the resolve).  NoResolve: the value comes from a k_resolve launch (or is not needed).
+struct NoResolve { static constexpr bool active = false; __device__ __forceinline__ uint64_t operator()() const { return 0ull; } };
 
 struct FromLw {
     const double* lw; double* w_out; const double* pm; const double* ps; const double* pq; int nb;
@@ -988,23 +1028,38 @@ struct FromLw {
 
 // The body of k_local for workgroup `bidx` of `nblk`; shared storage is handed in so that the batched small-filter kernel
 // (k_pf_batch: one workgroup runs a whole filter, nblk == 1) executes exactly this code.  MAXBL: capacity of the partials.
-template <int MODE, bool FROM_LW, int MAXBL, bool LIT = false>
+template <int MODE, bool FROM_LW, int MAXBL, bool LIT = false, class Pro = NoResolve>
 __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, double* es /* [MAXBL], FROM_LW only */, const int bidx, const int nblk,
                                             const double* __restrict__ w, long long nw, const double* __restrict__ ain,
                                             int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
-                                            const FromLw& f, const PassIn pin = PassIn{false, 1.0, 0.0})
+                                            const FromLw& f, const Pro pro = Pro(), double* __restrict__ ain_p_out = nullptr)
 {
     const int t = threadIdx.x;
     const long long b0 = (long long)bidx * EB;
     // run-state words and this lane's terms are fetched together (one memory round trip, not two)
     const int s_dead = st->dead, s_do = st->do_resample, dbg = st->debug_stop;
     const uint32_t s_flags = st->flags;
-    const double total = (MODE == MODE_P) ? (pin.given ? pin.total : b2d(st->total_bits)) : 1.0;
+    double total = (MODE == MODE_P && !Pro::active) ? b2d(st->total_bits) : 1.0;
     double vraw[EL];
     if (!FROM_LW) load_terms<MODE_W>(w, nw, 1.0, b0 + (long long)t * EL, vraw);
-    const double a_in_pre = FROM_LW ? 0.0 : (pin.given ? pin.a_in : ain[bidx]);
+    double a_in_pre = FROM_LW ? 0.0 : ain[bidx];
     if (s_dead || s_flags) return;
     if (!FROM_LW && !s_do) return;
+    if constexpr (Pro::active) {
+        // this pass's workgroups resolve the MODE_W pass before them themselves (exact total = sum(w)), with their own
+        // weight loads already in flight; `ain` holds the prefixes of w, this block's prefix of w / total is derived here
+        const uint64_t tb = pro();
+        const double tot = b2d(tb);
+        if (bidx == f.lead && t == 0) {
+            st->total_bits = tb;
+            if (tot == 0.0) atomicOr(&st->flags, FLAG_ZERO_SUM);       // src/resampling.cpp:8,22,49
+            if (!isfinite(tot)) atomicOr(&st->flags, FLAG_NONFINITE);
+        }
+        if (tot == 0.0 || !isfinite(tot)) return;
+        total = tot;
+        a_in_pre = a_in_pre / tot;
+        if (t == 0) ain_p_out[bidx] = a_in_pre;
+    }
     const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0)); (void)stamper;
     BSSM_STAMP(st, dbg, 2, FROM_LW ? 4 : 0, stamper);
     double v[EL];
@@ -1317,19 +1372,57 @@ __device__ __forceinline__ uint64_t block_out_exact(const BlockRec& br, const Si
 // ---------------------------------------------------------------------------
 // resolve_in_block: the grid-level resolve, run by EVERY workgroup of the consuming kernel for itself (B <= 2 NT blocks).
 // The records of a pass are tiny (64 B a block) and the resolve is a latency chain, not work: as a launch of its own
-// (k_resolve, one workgroup) it cost 6.4-7.4 us per pass at N = 2^20 -- launch, staging the records in LDS, a 16-wave
-// scan, the boundary walk -- with the other 255 CUs idle.  Here each consumer workgroup loads the records it needs straight
-// into registers (two per thread), scans them with its own 4 waves and walks the boundary chain once, while its own
-// weight / particle loads are already in flight.
+// (k_resolve, one workgroup) it cost 6.4-7.4 us per pass at N = 2^20 with the other 255 CUs idle.
+// Here each consumer workgroup loads the records it needs straight into registers (two per thread: one round trip), folds
+// them into PURE runs around its non-PURE blocks, scans the runs with its own four waves (seg_excl_scan_tail: a thread's run
+// BEHIND its last non-PURE block travels on, so every non-PURE block is exactly one link) and one wave walks the chain of
+// links (walk_chain_regs); every thread then checks its runs' windows against the exact states.
 // Returns the exact state after blocks [0, upto)   (upto == B in a MODE_W pass: total = sum(w), src/resampling.cpp:20).
-// Same scheme as k_resolve: a run of PURE blocks is a PURE chunk, anything else a boundary chunk; every PURE chunk verifies
-// that the exact state entering it lies inside its records' windows, otherwise one lane walks the blocks in order.
+// Anything the records do not cover (a window miss, three non-PURE blocks in one lane's range, more than 64 of them) falls
+// back to one lane walking the blocks in order: exact, merely slow.
 // ---------------------------------------------------------------------------
 struct ResolveSmem {
-    BlockRec bnd[64];                // the records of the boundary chunks' blocks, in walk order
+    BlockRec bnd[64];                // the non-PURE blocks' records, in walk order
+    Pure ex[64];                     // the PURE run folded in front of each
+    int ebidx[64];
+    uint64_t sout[65];               // exact state after link j (sout[j + 1]); sout[0] = 0
     __attribute__((aligned(16))) SideEntry sideC[64];
     uint64_t result;
+    int fail;
 };
+
+struct LaneRun { Pure p; long long wlo, whi; uint64_t base; int any; };      // a run of PURE blocks
+
+__device__ __forceinline__ void run_reset(LaneRun& r) { r.p.d0 = 0; r.p.d1 = 0; r.wlo = -(1ll << 40); r.whi = (1ll << 40); r.base = 0; r.any = 0; }
+__device__ __forceinline__ void run_fold(LaneRun& r, const Rec& pr)
+{
+    if (!r.any) { r.base = pr.base; r.any = 1; }
+    const long long m0 = (long long)(r.base + (uint64_t)r.p.d0 - pr.base);
+    const long long m1 = (long long)(r.base + 1 + (uint64_t)r.p.d1 - pr.base);
+    const long long mmin = m0 < m1 ? m0 : m1, mmax = m0 > m1 ? m0 : m1;
+    const long long lo = (long long)pr.lo - mmin + 2, hi = (long long)pr.hi - mmax - 2;
+    r.wlo = lo > r.wlo ? lo : r.wlo; r.whi = hi < r.whi ? hi : r.whi;
+    Pure q; q.d0 = (int64_t)(pr.o[0] - pr.base); q.d1 = (int64_t)(pr.o[1] - (pr.base + 1));
+    r.p = pure_compose(r.p, q);
+}
+// append the run q to the run r (same window algebra as a block record: q's window is relative to q.base)
+__device__ __forceinline__ void run_merge(LaneRun& r, const LaneRun& q)
+{
+    if (!q.any) return;
+    if (!r.any) { r = q; return; }
+    const long long m0 = (long long)(r.base + (uint64_t)r.p.d0 - q.base);
+    const long long m1 = (long long)(r.base + 1 + (uint64_t)r.p.d1 - q.base);
+    const long long mmin = m0 < m1 ? m0 : m1, mmax = m0 > m1 ? m0 : m1;
+    const long long lo = q.wlo - mmin + 2, hi = q.whi - mmax - 2;
+    r.wlo = lo > r.wlo ? lo : r.wlo; r.whi = hi < r.whi ? hi : r.whi;
+    r.p = pure_compose(r.p, q.p);
+}
+__device__ __forceinline__ bool run_ok(const LaneRun& r, uint64_t ent)
+{
+    if (!r.any) return true;
+    const long long diff = (long long)(ent - r.base);
+    return diff >= r.wlo && diff <= r.whi;
+}
 
 template <int MODE>
 __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& rs, const BlockRec* __restrict__ brec,
@@ -1342,148 +1435,119 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     const int dbg = st->debug_stop; (void)dbg;
     const bool stamper = (t == 0 && blockIdx.x == 100); (void)stamper;
     BSSM_STAMP(st, dbg, MODE, 0, stamper);
-    const int CB = (B + NT - 1) / NT;                  // blocks per thread: 1 or 2 (the caller guarantees B <= 2 NT)
+    // ---- all threads: thread t holds CB (1 or 2) consecutive blocks, straight from global memory into registers ----
+    const int CB = (B + NT - 1) / NT;                  // (the caller guarantees B <= 2 NT)
     const int c0 = t * CB, c1 = (c0 + CB < upto) ? c0 + CB : upto;
     BlockRec r0, r1;
     r0.prefix = rec_identity(0); r0.tail_from = NT; r0.nside = 0; r1 = r0;
     if (c0 < c1) r0 = brec[c0];
     if (c0 + 1 < c1) r1 = brec[c0 + 1];
-    // the last block of the range often carries one side entry (next to cum == 1.0 in a full pass): fetch it with the records
-    if (t >= NT - (int)(sizeof(SideEntry) / 16)) {
-        const int q = t - (NT - (int)(sizeof(SideEntry) / 16));
-        reinterpret_cast<uint4*>(&rs.sideC[63])[q] = reinterpret_cast<const uint4*>(&side[upto - 1].e[0])[q];
-    }
-    if (t == 0) sm.fail = 0;
-    // chunk record: PURE composite + validity window relative to the first block's base
-    bool isb = false;
-    Pure comp; comp.d0 = 0; comp.d1 = 0;
-    long long wlo = -(1ll << 40), whi = (1ll << 40);
-    uint64_t cbase = 0;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int b = c0 + i;
-        if (b < c1 && !isb) {
-            const BlockRec& r = i ? r1 : r0;
-            if (r.prefix.kind != REC_PURE || r.tail_from < NT || r.nside > 0) isb = true;
-            else {
-                if (i == 0) cbase = r.prefix.base;
-                const long long m0 = (long long)(cbase + (uint64_t)comp.d0 - r.prefix.base);
-                const long long m1 = (long long)(cbase + 1 + (uint64_t)comp.d1 - r.prefix.base);
-                const long long mmin = m0 < m1 ? m0 : m1, mmax = m0 > m1 ? m0 : m1;
-                const long long lo = (long long)r.prefix.lo - mmin + 2, hi = (long long)r.prefix.hi - mmax - 2;
-                wlo = lo > wlo ? lo : wlo; whi = hi < whi ? hi : whi;
-                Pure p; p.d0 = (int64_t)(r.prefix.o[0] - r.prefix.base); p.d1 = (int64_t)(r.prefix.o[1] - (r.prefix.base + 1));
-                comp = pure_compose(comp, p);
-            }
-        }
-    }
-    if (c0 >= c1) { isb = false; comp.d0 = comp.d1 = 0; }     // lanes past the range: identity
-    BSSM_STAMP(st, dbg, MODE, 1, stamper && comp.d0 != 1);
-    int seg, nb; Pure lastseg;
-    const Pure exc = seg_excl_scan<NT / 64>(sm, comp, isb, seg, nb, lastseg);
-    if (isb && seg < MAXBND) {
-        sm.bnd_excl[seg] = exc; sm.bnd_lane[seg] = t;
-        if (seg * CB + CB <= 64) { rs.bnd[seg * CB] = r0; if (CB > 1) rs.bnd[seg * CB + 1] = r1; }
+    if (t == 0) { rs.sout[0] = 0; rs.fail = 0; }
+    // head = the PURE run in front of the thread's first non-PURE block, tail = the run behind its last one
+    //   (P P): head = both | (X P): tail = block 1 | (P X): head = block 0 | (X X): neither
+    LaneRun head, tail;
+    run_reset(head); run_reset(tail);
+    const bool x0 = (c0 < c1) && !(r0.prefix.kind == REC_PURE && r0.tail_from >= NT && r0.nside == 0);
+    const bool x1 = (c0 + 1 < c1) && !(r1.prefix.kind == REC_PURE && r1.tail_from >= NT && r1.nside == 0);
+    if (c0 < c1 && !x0) run_fold(head, r0.prefix);
+    if (c0 + 1 < c1 && !x1) { if (x0) run_fold(tail, r1.prefix); else run_fold(head, r1.prefix); }
+    const int nent = (x0 ? 1 : 0) + (x1 ? 1 : 0);
+    int ent_before, E;
+    const Pure carry = seg_excl_scan_tail<NT / 64>(sm, nent ? tail.p : head.p, nent > 0, nent, ent_before, E);
+    const bool fits = (E <= 64);
+    // the links: every non-PURE block with the PURE run in front of it
+    if (fits && nent) {
+        int slot = ent_before;
+        if (x0) { rs.bnd[slot] = r0; rs.ebidx[slot] = c0; rs.ex[slot] = carry; slot++; }
+        if (x1) { rs.bnd[slot] = r1; rs.ebidx[slot] = c0 + 1; if (x0) { rs.ex[slot].d0 = 0; rs.ex[slot].d1 = 0; } else rs.ex[slot] = pure_compose(carry, head.p); }
     }
     __syncthreads();
     BSSM_STAMP(st, dbg, MODE, 2, stamper);
     long long lit = 0;
-    const int nent = nb * CB;
-    if (t < 64) {
-        // boundary walk.  One wave; lane j owns the j-th block of the boundary chunks with its record in registers; the
-        // exact state travels in scalar registers (walk_chain_regs), what the chain cannot take is stepped lane to lane.
+    if (fits && t < 64) {
+        // ---- boundary walk, one wave: lane j owns link j ----
         const int lane = t;
-        const bool fits = (nb <= MAXBND) && (nent <= 64);
-        const bool have = fits && lane < nent;
-        const int k = have ? lane / CB : 0;
+        const bool have = lane < E;
         int bidx = -1;
         Pure ex; ex.d0 = 0; ex.d1 = 0;
         Rec pr = rec_identity(0);
         int nside = 0;
         bool slow = false;
         if (have) {
-            bidx = sm.bnd_lane[k] * CB + (lane % CB);
-            if (bidx >= upto) bidx = -1;
-            if (lane % CB == 0) ex = sm.bnd_excl[k];
-        }
-        if (bidx >= 0) {
+            bidx = rs.ebidx[lane]; ex = rs.ex[lane];
             pr = rs.bnd[lane].prefix; nside = rs.bnd[lane].nside;
             slow = (nside > 1) || (rs.bnd[lane].tail_from < NT);
-            if (nside == 1 && !slow && !(bidx == upto - 1 && lane < 63)) {       // (the last block's entry is already in slot 63)
+            if (nside == 1 && !slow) {
                 const uint4* sp = reinterpret_cast<const uint4*>(&side[bidx].e[0]);
                 uint4* dp = reinterpret_cast<uint4*>(&rs.sideC[lane]);
 #pragma unroll
                 for (int q = 0; q < (int)(sizeof(SideEntry) / 16); q++) dp[q] = sp[q];
             }
         }
-        if (!fits) { if (lane == 0) sm.fail = 1; }
-        else {
-            uint64_t s = 0, my_out = 0, my_s0 = 0;
-            const bool special = (bidx >= 0) && (slow || nside == 1);
-            const StepFn fn = stepfn_build(ex, pr);          // "PURE run + this block's record" folded into constants
-            const WalkFn wfn = walkfn_from(fn, lane < nent && bidx >= 0 && !special);
-            BSSM_STAMP(st, dbg, MODE, 3, stamper && wfn.sh >= 0);
-            const int j0 = walk_chain_regs(wfn, nent, s, my_s0, my_out);
-            BSSM_STAMP(st, dbg, MODE, 4, stamper && s != 1);
-            for (int j = j0; j < nent; j++) {
-                bool ok;
-                uint64_t o = stepfn_apply(fn, s, ok);
-                const uint64_t e = pure_step(ex, s);         // (only lane j's copy is used)
-                if (bidx < 0) { o = e; ok = true; }
-                if (lane == j && (special || !ok)) {             // rare: side entry / tails / window miss
-                    bool done = false;
-                    if (!slow && ok && nside == 1) {
-                        const SideEntry& se = rs.sideC[(bidx == upto - 1) ? 63 : lane];
-                        bool ok2 = true;
-                        uint64_t o2 = rec_step(se.leaf, o, ok2);
-                        if (!ok2) {                          // HARD leaf: its 8 terms literally (kept in the entry)
-                            double c = b2d(o);
+        uint64_t sw = 0, my_out = 0, my_s0 = 0;
+        const bool special = have && (slow || nside == 1);
+        const StepFn fn = stepfn_build(ex, pr);          // "PURE run + this block's record" folded into constants
+        const WalkFn wfn = walkfn_from(fn, have && !special);
+        BSSM_STAMP(st, dbg, MODE, 3, stamper && wfn.sh >= 0);
+        const int j0 = walk_chain_regs(wfn, E, sw, my_s0, my_out);
+        BSSM_STAMP(st, dbg, MODE, 4, stamper && sw != 1);
+        for (int j = j0; j < E; j++) {
+            bool ok;
+            uint64_t o = stepfn_apply(fn, sw, ok);
+            const uint64_t e = pure_step(ex, sw);         // (only lane j's copy is used)
+            if (lane == j && (special || !ok)) {             // rare: side entry / tails / window miss
+                bool done = false;
+                if (!slow && ok && nside == 1) {
+                    const SideEntry& se = rs.sideC[lane];
+                    bool ok2 = true;
+                    uint64_t o2 = rec_step(se.leaf, o, ok2);
+                    if (!ok2) {                          // HARD leaf: its 8 terms literally (kept in the entry)
+                        double c = b2d(o);
 #pragma unroll
-                            for (int q = 0; q < EL; q++) c = c + se.terms[q];
-                            o2 = d2b(c);
-                        }
-                        done = true;
-                        if (se.pad) {
-                            const int64_t diff = (int64_t)(o2 - se.post_base);
-                            if (diff < (int64_t)se.lo || diff > (int64_t)se.hi) done = false;
-                            else { Pure pp; pp.d0 = se.d0; pp.d1 = se.d1; o2 = pure_step(pp, o2); }
-                        }
-                        if (done) o = o2;
+                        for (int q = 0; q < EL; q++) c = c + se.terms[q];
+                        o2 = d2b(c);
                     }
-                    if (!done) o = block_out_exact<MODE>(rs.bnd[lane], side, w, nw, total, bidx, e, lit);   // the general (slower) routine
+                    done = true;
+                    if (se.pad) {
+                        const int64_t diff = (int64_t)(o2 - se.post_base);
+                        if (diff < (int64_t)se.lo || diff > (int64_t)se.hi) done = false;
+                        else { Pure pp; pp.d0 = se.d0; pp.d1 = se.d1; o2 = pure_step(pp, o2); }
+                    }
+                    if (done) o = o2;
                 }
-                if (lane == j) my_out = o;
-                s = readlane_u64(o, j);
+                if (!done) o = block_out_exact<MODE>(rs.bnd[lane], side, w, nw, total, bidx, e, lit);   // the general (slower) routine
             }
-            BSSM_STAMP(st, dbg, MODE, 5, stamper && s != 1);
-            if (lane == 0) sm.seg_start[0] = 0;
-            if (have) {
-                if (lane % CB == CB - 1) sm.seg_start[k + 1] = my_out;
-                if (bidx == upto - 1) rs.result = my_out;
-            }
+            if (lane == j) my_out = o;
+            sw = readlane_u64(o, j);
         }
+        BSSM_STAMP(st, dbg, MODE, 5, stamper && sw != 1);
+        if (have) rs.sout[lane + 1] = my_out;
     }
+    if (!fits && t == 0) rs.fail = 1;
     __syncthreads();
     BSSM_STAMP(st, dbg, MODE, 6, stamper);
-    if (!sm.fail && c0 < c1 && !isb) {
-        const uint64_t ent = pure_step(exc, sm.seg_start[seg]);
-        const long long diff = (long long)(ent - cbase);
-        if (diff < wlo || diff > whi) sm.fail = 1;
-        else if (c1 == upto) {                               // this thread holds the last block of the range
-            uint64_t s = ent;
-            bool ok = true;
-            s = rec_step(r0.prefix, s, ok);
-            if (c0 + 1 < c1) s = rec_step(r1.prefix, s, ok);
-            if (!ok) sm.fail = 1; else rs.result = s;
+    // ---- all threads: the exact states entering the PURE runs must lie inside the runs' windows ----
+    if (fits && c0 < c1) {
+        const uint64_t ent = pure_step(carry, rs.sout[ent_before]);      // exact state at the thread's first block
+        bool ok = true;
+        uint64_t end;
+        if (nent == 0) { ok = run_ok(head, ent); end = pure_step(head.p, ent); }
+        else {
+            ok = run_ok(head, ent);                                      // (empty unless (P X))
+            const uint64_t after = rs.sout[ent_before + nent];            // exact state behind the thread's last non-PURE block
+            ok = ok && run_ok(tail, after);
+            end = pure_step(tail.p, after);
         }
+        if (!ok) rs.fail = 1;
+        if (c1 == upto) rs.result = end;                                 // this thread holds the last block of the range
     }
     __syncthreads();
-    if (sm.fail) {
+    if (rs.fail) {
         // the records did not cover the exact states: one lane walks every block (each step is still exact)
         if (t == 0) {
-            uint64_t s = 0;
-            for (int b = 0; b < upto; b++) { const BlockRec r = brec[b]; s = block_out_exact<MODE>(r, side, w, nw, total, b, s, lit); }
-            rs.result = s;
+            uint64_t sf = 0;
+            for (int b = 0; b < upto; b++) { const BlockRec r = brec[b]; sf = block_out_exact<MODE>(r, side, w, nw, total, b, sf, lit); }
+            rs.result = sf;
             if (count_stats) atomicAdd((unsigned long long*)&st->stat_serial_walks, 1ull);
         }
         __syncthreads();
@@ -1491,13 +1555,21 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     if (lit && count_stats) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
     BSSM_STAMP(st, dbg, MODE, 7, stamper);
 #ifdef BSSM_DEV_STAMPS
-    if ((dbg == 99 || dbg == 98) && stamper) { st->stamps[MODE][8] = nb; st->stamps[MODE][9] = upto; }
+    if ((dbg == 99 || dbg == 98) && stamper) { st->stamps[MODE][8] = E; st->stamps[MODE][9] = upto; }
 #endif
     return rs.result;
 }
 
-// prev_brec != nullptr (MODE_P only): this pass's workgroups resolve the MODE_W pass before them themselves -- exact
-// total = sum(w), their own approximate prefix of w / total -- instead of a k_resolve<W> launch in between.
+template <int MODE>
+struct InResolve {
+    static constexpr bool active = true;
+    SegSmem* sm; ResolveSmem* rs; const BlockRec* brec; const SideList* side; int B, upto;
+    const double* w; long long nw; double total; DevState* st; bool stats;
+    __device__ __forceinline__ uint64_t operator()() const { return resolve_in_block<MODE>(*sm, *rs, brec, side, B, upto, w, nw, total, st, stats); }
+};
+
+// INRES (MODE_P only): this pass's workgroups resolve the MODE_W pass before them themselves -- exact total = sum(w), their
+// own approximate prefix of w / total -- instead of a k_resolve<W> launch in between.
 // (INRES is a template parameter so that the plain variants keep their register budget: the resolve costs ~40 VGPRs)
 template <int MODE, bool FROM_LW, bool INRES = false>
 __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long long nw, const double* __restrict__ ain,
@@ -1509,26 +1581,16 @@ __global__ __launch_bounds__(NT) void k_local(const double* __restrict__ w, long
     __shared__ uint64_t tin[NT];
     __shared__ double es[1];
     const int bidx = (int)blockIdx.x + boff, nblk = nblk_g ? nblk_g : (int)gridDim.x;
-    PassIn pin; pin.given = false; pin.total = 1.0; pin.a_in = 0.0;
     if constexpr (INRES) {
         static_assert(!INRES || (MODE == MODE_P && !FROM_LW), "only the cumsum pass resolves the pass before it");
         __shared__ ResolveSmem rs;
-        {
-            const double ain_w = ain[bidx];
-            if (st->dead || st->flags || !st->do_resample) return;
-            const uint64_t tb = resolve_in_block<MODE_W>(sm, rs, prev_brec, prev_side, nblk, nblk, w, nw, 1.0, st, bidx == 0);
-            const double tot = b2d(tb);
-            if (bidx == f.lead && threadIdx.x == 0) {
-                st->total_bits = tb;
-                if (tot == 0.0) atomicOr(&st->flags, FLAG_ZERO_SUM);       // src/resampling.cpp:8,22,49
-                if (!isfinite(tot)) atomicOr(&st->flags, FLAG_NONFINITE);
-            }
-            if (tot == 0.0 || !isfinite(tot)) return;
-            pin.given = true; pin.total = tot; pin.a_in = ain_w / tot;
-            if (threadIdx.x == 0) ain_p_out[bidx] = pin.a_in;
-        }
+        InResolve<MODE_W> pro; pro.sm = &sm; pro.rs = &rs; pro.brec = prev_brec; pro.side = prev_side; pro.B = nblk; pro.upto = nblk;
+        pro.w = w; pro.nw = nw; pro.total = 1.0; pro.st = st; pro.stats = (bidx == 0);
+        local_block<MODE, FROM_LW, MAXB, false, InResolve<MODE_W>>(sm, tin, es, bidx, nblk, w, nw, ain, lim, brec, side, st, f, pro, ain_p_out);
+    } else {
+        (void)prev_brec; (void)prev_side; (void)ain_p_out;
+        local_block<MODE, FROM_LW, MAXB>(sm, tin, es, bidx, nblk, w, nw, ain, lim, brec, side, st, f);
     }
-    local_block<MODE, FROM_LW, MAXB>(sm, tin, es, bidx, nblk, w, nw, ain, lim, brec, side, st, f, pin);
 }
 
 constexpr int NTR = 1024;        // threads of the single resolve workgroup (16 waves)
@@ -1784,10 +1846,10 @@ __device__ __attribute__((noinline)) double2 expand_by_search(const int* Tl, int
 
 constexpr int CAPX = 3072;       // outputs a block can stage in LDS for the coalesced store (it owns ~EB of them)
 
-template <int KIND, bool LIT = false>
+template <int KIND, bool LIT = false, class Pro = NoResolve>
 __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
                                             const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [nstage][CAPX] or nullptr */, const int nstage = 0,
-                                            const bool has_cin = false, const uint64_t cin_val = 0)
+                                            const Pro pro = Pro())
 {
     const int t = threadIdx.x;
     const long long b0 = (long long)bidx * EB;
@@ -1818,8 +1880,12 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         }
     }
     const double a_in_p = a.ain_p[bidx];
-    const uint64_t cinb = has_cin ? cin_val : a.cin[bidx];
+    const uint64_t cin_ld = Pro::active ? 0ull : a.cin[bidx];
     if (s_dead || !s_do || s_flags) return;
+    // (INRES: every workgroup resolves the MODE_P pass for itself -- its own exact incoming state -- while its weight and
+    //  particle loads are in flight; the resolve's scratch borrows the staging area, which is not in use yet)
+    const uint64_t cinb = Pro::active ? pro() : cin_ld;
+    if (Pro::active) __syncthreads();
     if (t == 0) sm.big = 0;
     // the uniform(s) of this resample call (systematic: one draw; computed here, under the load latency)
     UniformSrc us;
@@ -1987,17 +2053,14 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st, const B
     __shared__ int Tl[EB];
     __shared__ int Tbegin;
     extern __shared__ __attribute__((aligned(16))) double lx[];      // [a.nstage][CAPX], sized by the launch
-    bool has_cin = false;
-    uint64_t cin_val = 0;
     if constexpr (INRES) {
-        // (the resolve's scratch lives in the staging area, which is not in use yet: the launch sizes the dynamic LDS for both)
-        ResolveSmem& rs = *reinterpret_cast<ResolveSmem*>(lx);
-        if (st->dead || !st->do_resample || st->flags) return;
-        cin_val = resolve_in_block<MODE_P>(sm, rs, prev_brec, prev_side, nblk, bidx, a.w, a.nw, b2d(st->total_bits), st, bidx == nblk - 1);
-        has_cin = true;
-        __syncthreads();                                             // the staging area is free again
+        InResolve<MODE_P> pro; pro.sm = &sm; pro.rs = reinterpret_cast<ResolveSmem*>(lx); pro.brec = prev_brec; pro.side = prev_side;
+        pro.B = nblk; pro.upto = bidx; pro.w = a.w; pro.nw = a.nw; pro.total = b2d(st->total_bits); pro.st = st; pro.stats = (bidx == nblk - 1);
+        apply_block<KIND, false, InResolve<MODE_P>>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage, pro);
+    } else {
+        (void)prev_brec; (void)prev_side;
+        apply_block<KIND>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage);
     }
-    apply_block<KIND>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage, has_cin, cin_val);
 }
 
 // multinomial: inverse CDF on the exact cum_sum (distributional parity only)

@@ -18,4 +18,4 @@ def test_randomized_stress(tool, seed):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     last = out.stdout.strip().splitlines()[-1]
     assert "mismatches 0" in last and "MISMATCH" not in out.stdout, out.stdout[-2000:]
-    assert int(last.split()[1]) >= 20, last            # it did run a meaningful number of cases
+    assert int(last.split()[1]) >= 20, last            # compared cases (configurations a tool refuses to run are not counted)

@@ -20,7 +20,7 @@ print('k_weights block 100: start->prologue', kw[8]-kw[4], 'prologue->weights', 
 names = ["k_resolve<W>: start, plan, staged, chunk, scan, walk, sync, final", "k_resolve<P>", "k_weights/k_local block 100: [0]start [1]loaded [2]scan [3]minmax ... [8]prologue [9]weights", "k_apply block 100: start, load, scan, resolve, T, expand, se"]
 for r in (0, 1):
     q = st[r]
-    print('in-kernel resolve', 'W (in k_local<P>, block 100, upto=B)' if r == 0 else 'P (in k_apply, block 100)', 'load+chunk', q[1]-q[0], 'scan', q[2]-q[1], 'setup', q[3]-q[2], 'chain', q[4]-q[3], 'general loop', q[5]-q[4], 'sync', q[6]-q[5], 'verify', q[7]-q[6], 'total', q[7]-q[0], 'nb', q[8], 'upto', q[9])
+    print('in-kernel resolve', 'W (in k_local<P>, block 100, upto=B)' if r == 0 else 'P (in k_apply, block 100)', 'load + classify + scan + links', q[2]-q[0], 'setup', q[3]-q[2], 'chain', q[4]-q[3], 'general loop', q[5]-q[4], 'barrier', q[6]-q[5], 'verify', q[7]-q[6], 'total', q[7]-q[0], 'links', q[8], 'upto', q[9])
 ap = st[3]
 print('k_apply block 100 expand detail: T->Tb sync', ap[7]-ap[4], 'any_big sync', ap[8]-ap[7], 'emission', ap[9]-ap[8], 'barrier', ap[10]-ap[9], 'store loop', ap[5]-ap[10])
 for r in range(4):
