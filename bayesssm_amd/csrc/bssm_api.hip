@@ -54,6 +54,9 @@ struct bssm_ctx {
     int opt_batch_lit_max = 384;   // largest N that takes the in-order exact sums in k_pf_batch
     int opt_stage = 1;             // LDS staging of k_apply's particle stores
     int opt_inkernel_resolve = 1;  // grids of <= 2 NT blocks: resolve inside the consuming kernels instead of k_resolve launches
+    int opt_fuse_step = 0;         // SISR bootstrap filters: the next observation's transition + weight inside the expansion kernel
+                                   // (off: measured slower -- 7 generator pairs per lane at 2 waves per SIMD cost the expansion kernel 7.7 us,
+                                   //  the k_step launch they replace costs 11.2 us but the per-block partials still need a 5.4 us launch)
     int opt_debug_stop = 0;        // DEV builds: stage stamps (99 typical block, 98 head block, 97 batched kernel)
     // growable buffers
     std::map<std::string, std::pair<void*, size_t>> pool;
@@ -152,6 +155,9 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
+    for (const void* fnp : {reinterpret_cast<const void*>(&k_apply<0, true, true>), reinterpret_cast<const void*>(&k_apply<0, false, true>),
+                            reinterpret_cast<const void*>(&k_apply<1, true, true>), reinterpret_cast<const void*>(&k_apply<1, false, true>)})
+        if (e == hipSuccess) e = hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
     static_assert(sizeof(ResolveSmem) <= 3 * CAPX * sizeof(double), "the in-kernel resolve borrows k_apply's staging area");
     if (e != hipSuccess) {
         g_err = std::string("bssm_ctx_create: ") + hipGetErrorString(e);
@@ -198,6 +204,7 @@ extern "C" int bssm_ctx_set_option(bssm_ctx* c, int option, int value)
         case BSSM_OPT_STAGE_EXPANSION: c->opt_stage = value; break;
         case BSSM_OPT_INKERNEL_RESOLVE: c->opt_inkernel_resolve = value; break;
         case BSSM_OPT_DEBUG_STOP: c->opt_debug_stop = value; break;
+        case BSSM_OPT_FUSE_STEP: c->opt_fuse_step = value; break;
         default: ARGFAIL("bssm_ctx_set_option: unknown option");
     }
     return BSSM_OK;
@@ -280,6 +287,8 @@ struct ResampleLaunch {
     int* d_anc; long long anc_stride; double* d_cum;
     const double* xsrc; double* xdst; int dim; long long xstride;
     const double* auxsrc; double* auxdst; double* se_part;
+    // the next observation's transition + weight fused into the expansion (k_apply<.., STEP>): model id or -1
+    int step_model = -1; ModelPar step_par; double step_y = 0; NoiseSrc step_ns;
 };
 
 static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
@@ -331,10 +340,18 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     a.auxsrc = r.auxsrc; a.auxdst = r.auxdst; a.se_part = r.se_part;
     // LDS staging for the coalesced particle store: one array per thing carried to the outputs
     a.lead = boff; a.last = boff + G - 1;
+    a.step_model = r.step_model; a.step_par = r.step_par; a.step_y = r.step_y; a.step_ns = r.step_ns; a.step_lw = c->lw;
     a.nstage = (c->opt_stage && r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
     const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), inres ? sizeof(ResolveSmem) : (size_t)0);
-    if (r.kind == BSSM_SYSTEMATIC) { if (inres) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); else LAUNCH(c, "k_apply<systematic>", (k_apply<1, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); }
-    else if (r.kind == BSSM_STRATIFIED) { if (inres) LAUNCH(c, "k_apply<stratified>(+resolve<P>)", (k_apply<0, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); else LAUNCH(c, "k_apply<stratified>", (k_apply<0, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); }
+    const bool step = r.step_model >= 0;
+#define APPLY(K, NAME) do { \
+        if (inres && step) LAUNCH(c, "k_apply+step<" NAME ">(+resolve<P>)", (k_apply<K, true, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); \
+        else if (inres) LAUNCH(c, "k_apply<" NAME ">(+resolve<P>)", (k_apply<K, true, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); \
+        else if (step) LAUNCH(c, "k_apply+step<" NAME ">", (k_apply<K, false, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); \
+        else LAUNCH(c, "k_apply<" NAME ">", (k_apply<K, false, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); } while (0)
+    if (r.kind == BSSM_SYSTEMATIC) APPLY(1, "systematic");
+    else if (r.kind == BSSM_STRATIFIED) APPLY(0, "stratified");
+#undef APPLY
     else {
         if (inres) LAUNCH(c, "k_apply<cum>(+resolve<P>)", (k_apply<2, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); else LAUNCH(c, "k_apply<cum>", (k_apply<2, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg);
         const int Bo = (int)(((long long)r.n + EB - 1) / EB);
@@ -637,6 +654,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         }
     }
     int ktrans = 0, prev_t = 0;
+    bool stepped_ahead = false;
     for (int i = 1; i <= T; i++) {                                                        // :123
         const int ot = cfg->obs_times ? cfg->obs_times[i - 1] : i;
         const int gap = ot - prev_t;                                                      // :124
@@ -648,11 +666,26 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         r.d_w = c->w; r.nw = N; r.n = (int)N; r.kind = cfg->resample_fn; r.d_u = (const double*)d_ur; r.u_stride = u_stride; r.key = key;
         r.d_anc = (int*)d_anc; r.anc_stride = N; r.d_cum = nullptr; r.dim = dim; r.xstride = N;
         // gap transitions; the last one is fused with the weight evaluation unless APF  (:125-136)
-        for (int step = 1; step <= gap; step++) {
+        if (stepped_ahead) {
+            // this observation's (single) transition and its log-weights were computed inside the previous observation's
+            // expansion kernel; what is left of k_step are the per-block log-sum-exp partials
+            next_gmax();
+            LAUNCH(c, "k_lw_partials", k_lw_partials, B, NTS, 0, c->lw, N, c->pm, c->ps, c->pq, c->gmax_cur);
+            ktrans++;
+        } else for (int step = 1; step <= gap; step++) {
             const bool fuse_w = (!apf && step == gap);
             if (fuse_w) next_gmax();
             launch_step_model(c, cfg->model, true, fuse_w ? 1 : 0, false, X0, N, B, par, yi, noise(ktrans));
             ktrans++;
+        }
+        // can the NEXT observation's transition + weight ride along with this observation's expansion?  (bootstrap filter
+        // that resamples at every observation, a single transition to the next observation, nothing that needs the
+        // resampled particles themselves in HBM)
+        stepped_ahead = false;
+        if (c->opt_fuse_step && !apf && !rmpf && !sir && resample_algorithm == BSSM_SISR && i < T && !cfg->return_particles &&
+            !cfg->return_ancestors && (cfg->resample_fn == BSSM_STRATIFIED || cfg->resample_fn == BSSM_SYSTEMATIC)) {
+            const int next_gap = (cfg->obs_times ? cfg->obs_times[i] : i + 1) - ot;
+            stepped_ahead = (next_gap == 1);
         }
         if (apf) {                                                                        // :140-175
             next_gmax();
@@ -677,6 +710,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         r.d_lw = c->lw; r.plan = PLAN_PF; r.check_degenerate = 1; r.obs_i = i; r.resample_algorithm = resample_algorithm;
         r.threshold = threshold; r.d_ess = (double*)d_ess; r.d_llh = (double*)d_llh; r.d_resampled = (int*)d_resampled;
         r.xsrc = X0; r.xdst = X1; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = se_row;
+        if (stepped_ahead) { r.step_model = cfg->model; r.step_par = par; r.step_y = cfg->y[i]; r.step_ns = noise(ktrans); }
         launch_scan_and_apply(c, r);
         if (resample_algorithm != BSSM_SISR)
             LAUNCH(c, "k_carry", k_carry, B, NT, 0, X0, X1, c->w, N, dim, se_row, c->st, 0);
@@ -754,7 +788,7 @@ extern "C" int bssm_pf_weigh_resample(bssm_ctx* c, long long n, const double* lw
     if (U) { if ((rc = pool_get(c, "wr_u", (size_t)nu * 8, &d_u))) return rc; HIPCHK(hipMemcpyAsync(d_u, U, (size_t)nu * 8, hipMemcpyHostToDevice, c->stream)); }
     HIPCHK(hipMemsetAsync(d_small, 0, 64, c->stream));
     LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
-    LAUNCH(c, "k_lw_partials", k_lw_partials, B, NTS, 0, c->lw, n, c->pm, c->ps, c->pq);
+    LAUNCH(c, "k_lw_partials", k_lw_partials, B, NTS, 0, c->lw, n, c->pm, c->ps, c->pq, (unsigned long long*)nullptr);
     c->gmax_cur = nullptr;
     ResampleLaunch r;
     r.d_lw = c->lw; r.plan = always ? PLAN_AUX : PLAN_PF; r.check_degenerate = always ? 0 : 1; r.obs_i = 1;
@@ -899,7 +933,7 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
             a.w = c->w; a.nw = N; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = (int)N;
             a.u_base = (const double*)d_ur; a.u_stride = u_stride; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;
             a.xsrc = X0; a.xdst = X1; a.dim = 1; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = se_row;
-            a.lead = boff; a.last = boff + nloc - 1;
+            a.lead = boff; a.last = boff + nloc - 1; a.step_model = -1; a.step_lw = nullptr;
             a.nstage = c->opt_stage ? 1 : 0;
             const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), sizeof(ResolveSmem));
             if (cfg->resample_fn == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), nloc, NT, xshm, a, c->st, c->brec_p, c->side_p, boff, B);

@@ -406,7 +406,8 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
 // closure mode: the model's log_likelihood_fn ran on the host (R/particle_filter_core.R:177-183), the normalisation,
 // log-likelihood, ESS, resample decision and resampling (:204-224) run here.  Same block shape and reduction order as k_step.
 __global__ __launch_bounds__(NTS) void k_lw_partials(const double* __restrict__ lw, long long N, double* __restrict__ pm,
-                                                     double* __restrict__ ps, double* __restrict__ pq)
+                                                     double* __restrict__ ps, double* __restrict__ pq,
+                                                     unsigned long long* __restrict__ gmax)
 {
     __shared__ double sh[NTS / 64];
     const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(NTS) void k_lw_partials(const double* __restrict__ 
     }
     s = block_sum_n<NTS / 64>(s, sh);
     q = block_sum_n<NTS / 64>(q, sh);
-    if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; }
+    if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; if (gmax) atomicMax(gmax + (blockIdx.x % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
 }
 
 // SIR variant of k_step (state dimension 2, data-dependent Gillespie loop: VALU/divergence-bound, not HBM-bound)
@@ -1814,6 +1815,9 @@ struct ApplyArgs {
     double* se_part;              // [B][dim] partial sums of x * (1/N) after resampling, or nullptr
     int nstage;                   // k_apply: LDS staging arrays provided by the launch (0..3 x CAPX doubles)
     int lead, last;               // first / last block of this launch in the global numbering: they record the launch's output range
+    // STEP kernels: the NEXT observation's transition_fn + weight_fn (R/particle_filter_core.R:127,177-183) applied to the
+    // resampled particles before they leave the workgroup -- what k_step would do in a launch of its own
+    int step_model; ModelPar step_par; double step_y; NoiseSrc step_ns; double* step_lw;
 };
 
 // Expansion when an element owns more than 64 outputs (degenerate weights: a few particles own almost everything): all
@@ -1846,7 +1850,7 @@ __device__ __attribute__((noinline)) double2 expand_by_search(const int* Tl, int
 
 constexpr int CAPX = 3072;       // outputs a block can stage in LDS for the coalesced store (it owns ~EB of them)
 
-template <int KIND, bool LIT = false, class Pro = NoResolve>
+template <int KIND, bool LIT = false, class Pro = NoResolve, bool STEP = false>
 __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
                                             const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [nstage][CAPX] or nullptr */, const int nstage = 0,
                                             const Pro pro = Pro())
@@ -1962,6 +1966,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
     // neighbouring lanes own neighbouring output ranges, and nothing has to be gathered.  Otherwise (degenerate
     // weights: a few particles own almost everything): all lanes share the work through a binary search in the counts.
     const int any_big = sm.big;
+    bool step_in_place = false; (void)step_in_place;
     BSSM_STAMP(st, dbg, 3, 8, stamper);
     if (!any_big) {
         // Scattered 8-byte stores cost the CU one address per lane (64 cache lines per wave instruction): with the
@@ -2017,7 +2022,34 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
 #pragma unroll
                 for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; xv[r] = (i < Te) ? lx[i - Tb] : 0.0; }
 #pragma unroll
-                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; if (i < Te) { a.xdst[i] = xv[r]; acc0 += xv[r] * invN; } }
+                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; if (i < Te) { if (!STEP) a.xdst[i] = xv[r]; acc0 += xv[r] * invN; } }
+                if constexpr (STEP) {
+                    // the next observation's transition + weight on the staged particles, a PAIR of outputs per lane (the
+                    // generator gives two normals per block, keyed by the pair's index -- exactly k_step's arithmetic);
+                    // a pair cut by the range's ends is finished by the neighbouring workgroup
+                    constexpr int R2 = (CAPX / 2 + 1 + NT - 1) / NT;
+                    const int q0 = Tb >> 1;
+#pragma unroll
+                    for (int r = 0; r < R2; r++) {
+                        const int q = q0 + t + NT * r, i0 = 2 * q, i1 = i0 + 1;
+                        const bool v0 = (i0 >= Tb && i0 < Te), v1 = (i1 >= Tb && i1 < Te);
+                        if (v0 || v1) {
+                            double x0 = v0 ? lx[i0 - Tb] : 0.0, x1 = v1 ? lx[i1 - Tb] : 0.0;
+                            double z0, z1;
+                            if (a.step_ns.arr) { z0 = v0 ? a.step_ns.arr[i0] : 0.0; z1 = v1 ? a.step_ns.arr[i1] : 0.0; }
+                            else normal_pair(a.step_ns.key, a.step_ns.purpose, a.step_ns.call, 0, (uint32_t)q, z0, z1);
+                            if (a.step_model == 1) { x0 = Model<1>::transition(x0, z0, a.step_par); x1 = Model<1>::transition(x1, z1, a.step_par); }
+                            else { x0 = Model<0>::transition(x0, z0, a.step_par); x1 = Model<0>::transition(x1, z1, a.step_par); }
+                            const double l0 = r_dnorm_log(a.step_y, x0, a.step_par.sy, a.step_par.log_sy);
+                            const double l1 = r_dnorm_log(a.step_y, x1, a.step_par.sy, a.step_par.log_sy);
+                            if (v0 && v1) {
+                                double2 qx; qx.x = x0; qx.y = x1; *reinterpret_cast<double2*>(a.xdst + i0) = qx;
+                                double2 ql; ql.x = l0; ql.y = l1; *reinterpret_cast<double2*>(a.step_lw + i0) = ql;
+                            } else if (v0) { a.xdst[i0] = x0; a.step_lw[i0] = l0; }
+                            else { a.xdst[i1] = x1; a.step_lw[i1] = l1; }
+                        }
+                    }
+                }
                 if (a.dim > 1) for (int i = Tb + t; i < Te; i += NT) { const double x1 = lx1[i - Tb]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
                 if (a.auxdst) for (int i = Tb + t; i < Te; i += NT) a.auxdst[i] = lxa[i - Tb];
             } else {
@@ -2025,11 +2057,34 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
                     acc0 += a.xdst[i] * invN;
                     if (a.dim > 1) acc1 += a.xdst[a.xstride + i] * invN;
                 }
+                if constexpr (STEP) step_in_place = true;
             }
         }
     } else {
         const double2 r = expand_by_search(Tl, anc, a.xsrc, a.xdst, a.dim, a.xstride, a.auxsrc, a.auxdst, b0, Tb, Te, invN);
         acc0 = r.x; acc1 = r.y;
+        if constexpr (STEP) step_in_place = true;
+    }
+    if constexpr (STEP) {
+        if (step_in_place) {
+            // (the resampled particles of this workgroup's range went to global memory -- too many outputs to stage, or
+            //  degenerate weights: the next observation's transition + weight in place, after everyone has read them)
+            __syncthreads();
+            for (int q = (Tb >> 1) + t; 2 * q < Te; q += NT) {
+                const int i0 = 2 * q, i1 = i0 + 1;
+                const bool v0 = (i0 >= Tb && i0 < Te), v1 = (i1 >= Tb && i1 < Te);
+                if (v0 || v1) {
+                    double x0 = v0 ? a.xdst[i0] : 0.0, x1 = v1 ? a.xdst[i1] : 0.0;
+                    double z0, z1;
+                    if (a.step_ns.arr) { z0 = v0 ? a.step_ns.arr[i0] : 0.0; z1 = v1 ? a.step_ns.arr[i1] : 0.0; }
+                    else normal_pair(a.step_ns.key, a.step_ns.purpose, a.step_ns.call, 0, (uint32_t)q, z0, z1);
+                    if (a.step_model == 1) { x0 = Model<1>::transition(x0, z0, a.step_par); x1 = Model<1>::transition(x1, z1, a.step_par); }
+                    else { x0 = Model<0>::transition(x0, z0, a.step_par); x1 = Model<0>::transition(x1, z1, a.step_par); }
+                    if (v0) { a.xdst[i0] = x0; a.step_lw[i0] = r_dnorm_log(a.step_y, x0, a.step_par.sy, a.step_par.log_sy); }
+                    if (v1) { a.xdst[i1] = x1; a.step_lw[i1] = r_dnorm_log(a.step_y, x1, a.step_par.sy, a.step_par.log_sy); }
+                }
+            }
+        }
     }
     BSSM_STAMP(st, dbg, 3, 5, stamper);
     if (a.se_part) {
@@ -2043,7 +2098,8 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
 
 // prev_brec != nullptr: every workgroup resolves the MODE_P pass for itself (its own exact incoming state) instead of a
 // k_resolve<P> launch in between.
-template <int KIND, bool INRES = false>
+// STEP: the next observation's transition_fn + weight_fn run on the resampled particles before they leave the workgroup.
+template <int KIND, bool INRES = false, bool STEP = false>
 __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st, const BlockRec* __restrict__ prev_brec,
                                               const SideList* __restrict__ prev_side, int boff, int nblk_g)
 {
@@ -2056,10 +2112,10 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st, const B
     if constexpr (INRES) {
         InResolve<MODE_P> pro; pro.sm = &sm; pro.rs = reinterpret_cast<ResolveSmem*>(lx); pro.brec = prev_brec; pro.side = prev_side;
         pro.B = nblk; pro.upto = bidx; pro.w = a.w; pro.nw = a.nw; pro.total = b2d(st->total_bits); pro.st = st; pro.stats = (bidx == nblk - 1);
-        apply_block<KIND, false, InResolve<MODE_P>>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage, pro);
+        apply_block<KIND, false, InResolve<MODE_P>, STEP>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage, pro);
     } else {
         (void)prev_brec; (void)prev_side;
-        apply_block<KIND>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage);
+        apply_block<KIND, false, NoResolve, STEP>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage);
     }
 }
 
@@ -2578,7 +2634,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             ApplyArgs aa;
             aa.w = LW; aa.nw = N; aa.ain_p = &ainp1; aa.cin = &cin1; aa.lim = g.lim; aa.n = (int)N;
             aa.u_base = nullptr; aa.u_stride = 0; aa.key = key; aa.anc_out = nullptr; aa.anc_stride = 0; aa.cum_out = nullptr;
-            aa.xsrc = xa; aa.xdst = xb; aa.dim = D; aa.xstride = N; aa.auxsrc = AUXLW; aa.auxdst = AUXG; aa.se_part = nullptr; aa.nstage = 0; aa.lead = 0; aa.last = 0;
+            aa.xsrc = xa; aa.xdst = xb; aa.dim = D; aa.xstride = N; aa.auxsrc = AUXLW; aa.auxdst = AUXG; aa.se_part = nullptr; aa.nstage = 0; aa.lead = 0; aa.last = 0; aa.step_model = -1; aa.step_lw = nullptr;
             if (g.resample_fn == 1) {
                 if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, aa, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, aa, &st);
             } else if (g.resample_fn == 0) {
@@ -2623,7 +2679,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         ApplyArgs a;
         a.w = LW; a.nw = N; a.ain_p = &ainp1; a.cin = &cin1; a.lim = g.lim; a.n = (int)N;
         a.u_base = nullptr; a.u_stride = 0; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;
-        a.xsrc = xa; a.xdst = xb; a.dim = D; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = sep; a.nstage = 0; a.lead = 0; a.last = 0;
+        a.xsrc = xa; a.xdst = xb; a.dim = D; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = sep; a.nstage = 0; a.lead = 0; a.last = 0; a.step_model = -1; a.step_lw = nullptr;
         if (g.resample_fn == 1) {                                                         // systematic
             if (lit) apply_block<1, true>(sm, tin, Tl, Tbegin, 0, 1, a, &st); else apply_block<1, false>(sm, tin, Tl, Tbegin, 0, 1, a, &st);
         } else if (g.resample_fn == 0) {                                                  // stratified

@@ -446,3 +446,33 @@ def test_r_seeded_bootstrap_filter_multinomial(B, ctx, oracle, ra):
         _compare(res, ref, N)
         anc = res["_extras"]["ancestors"]
         assert anc.shape == ref["ancestors"].shape and (anc == ref["ancestors"]).mean() > 0.99
+
+
+@pytest.mark.parametrize("model", ["lg", "ar1sin"])
+@pytest.mark.parametrize("rf", ["stratified", "systematic"])
+def test_fused_step_equals_separate_launch(B, oracle, model, rf):
+    """Option fuse_step: SISR bootstrap filters run the next observation's transition_fn + weight_fn inside the expansion
+    kernel (k_apply<.., STEP>) instead of a k_step launch of their own (off by default: measured slower): same arithmetic on the same draws, so every output must be
+    bit-identical with the option off -- device generator and injected draws, ragged N, gaps in obs_times (which fall back
+    to the separate launch for the affected observations), degenerate weights (the unstaged in-place path)."""
+    cx = B.Context(0, 1 << 17, 1)
+    m = B.models.linear_gaussian() if model == "lg" else B.models.ar1_sin()
+    rng = np.random.default_rng(7)
+    for N, T, ot in ((50001, 12, None), (4097, 9, [1, 2, 3, 5, 6, 7, 9, 10, 11]), (300, 6, None), (1 << 17, 5, None)):
+        ys = _simulate(rng, T, sin=(model == "ar1sin"))
+        if N == 300:
+            ys[2] = 6.0                   # a far-out observation: a handful of particles own nearly every output
+        kw = dict(resample_algorithm="SISR", resample_fn=rf, return_particles=False, obs_times=ot, phi=0.8, sigma_x=1.0, sigma_y=0.2 if N == 300 else 1.0)
+        outs = []
+        for fuse in (1, 0):
+            cx.set_option("fuse_step", fuse)
+            a = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, seed=5, stream=N, ctx=cx, **kw)
+            d = _draws(rng if False else np.random.default_rng(N), oracle, "BPF", T, N, rf, ot)
+            b2 = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, draws=d, ctx=cx, **kw)
+            outs.append((a, b2))
+        for k in (0, 1):
+            assert outs[0][k]["loglike"] == outs[1][k]["loglike"]
+            for key in ("loglike_history", "ess", "state_est"):
+                assert (outs[0][k][key] == outs[1][k][key]).all(), (N, key)
+    cx.set_option("fuse_step", 0)
+    cx.close()
