@@ -282,6 +282,10 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": kern[dom]["avg_us"]}
+            if "+resolve" in dom:
+                out["roofline"]["note"] = ("this launch also contains the grid-level resolve of the pass before it, a separate "
+                                           "single-workgroup launch until round 1 (k_resolve, 6.4-7.4 us): its duration is not "
+                                           "comparable with round 1's k_apply alone; the whole-sweep figure is sweep.frac_of_hbm_peak")
         else:
             out["roofline"] = {"bound": "hbm", "kernel": "whole sweep", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None}
