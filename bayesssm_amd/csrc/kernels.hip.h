@@ -1444,6 +1444,12 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     if (c0 < c1) r0 = brec[c0];
     if (c0 + 1 < c1) r1 = brec[c0 + 1];
     if (t == 0) { rs.sout[0] = 0; rs.fail = 0; }
+    // the last block of a full pass nearly always carries one side entry (the lanes next to cum == 1.0 are never PURE):
+    // fetch it now, with the records, so that the walk does not wait for a dependent global load later
+    if (upto == B && t >= NT - (int)(sizeof(SideEntry) / 16)) {
+        const int q = t - (NT - (int)(sizeof(SideEntry) / 16));
+        reinterpret_cast<uint4*>(&rs.sideC[63])[q] = reinterpret_cast<const uint4*>(&side[upto - 1].e[0])[q];
+    }
     // head = the PURE run in front of the thread's first non-PURE block, tail = the run behind its last one
     //   (P P): head = both | (X P): tail = block 1 | (P X): head = block 0 | (X X): neither
     LaneRun head, tail;
@@ -1478,13 +1484,14 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
             bidx = rs.ebidx[lane]; ex = rs.ex[lane];
             pr = rs.bnd[lane].prefix; nside = rs.bnd[lane].nside;
             slow = (nside > 1) || (rs.bnd[lane].tail_from < NT);
-            if (nside == 1 && !slow) {
+            if (nside == 1 && !slow && !(upto == B && bidx == B - 1 && lane < 63)) {      // (the last block's entry is already in slot 63)
                 const uint4* sp = reinterpret_cast<const uint4*>(&side[bidx].e[0]);
                 uint4* dp = reinterpret_cast<uint4*>(&rs.sideC[lane]);
 #pragma unroll
                 for (int q = 0; q < (int)(sizeof(SideEntry) / 16); q++) dp[q] = sp[q];
             }
         }
+        const int side_slot = (upto == B && bidx == B - 1 && lane < 63) ? 63 : lane;
         uint64_t sw = 0, my_out = 0, my_s0 = 0;
         const bool special = have && (slow || nside == 1);
         const StepFn fn = stepfn_build(ex, pr);          // "PURE run + this block's record" folded into constants
@@ -1499,7 +1506,7 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
             if (lane == j && (special || !ok)) {             // rare: side entry / tails / window miss
                 bool done = false;
                 if (!slow && ok && nside == 1) {
-                    const SideEntry& se = rs.sideC[lane];
+                    const SideEntry& se = rs.sideC[side_slot];
                     bool ok2 = true;
                     uint64_t o2 = rec_step(se.leaf, o, ok2);
                     if (!ok2) {                          // HARD leaf: its 8 terms literally (kept in the entry)
