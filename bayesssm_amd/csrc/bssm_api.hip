@@ -54,6 +54,8 @@ struct bssm_ctx {
     int opt_batch_lit_max = 384;   // largest N that takes the in-order exact sums in k_pf_batch
     int opt_stage = 1;             // LDS staging of k_apply's particle stores
     int opt_inkernel_resolve = 1;  // grids of <= 2 NT blocks: resolve inside the consuming kernels instead of k_resolve launches
+    int opt_renormalize = 1;       // filters: 1 = the resampler divides the normalised weights by their exact sum again (src/resampling.cpp:24,51),
+                                   // 0 = that division (by 1 +- a few 1e-14) is folded away: one exact pass instead of two
     int opt_fuse_step = 0;         // SISR bootstrap filters: the next observation's transition + weight inside the expansion kernel
                                    // (off: measured slower -- 7 generator pairs per lane at 2 waves per SIMD cost the expansion kernel 7.7 us,
                                    //  the k_step launch they replace costs 11.2 us but the per-block partials still need a 5.4 us launch)
@@ -205,6 +207,7 @@ extern "C" int bssm_ctx_set_option(bssm_ctx* c, int option, int value)
         case BSSM_OPT_INKERNEL_RESOLVE: c->opt_inkernel_resolve = value; break;
         case BSSM_OPT_DEBUG_STOP: c->opt_debug_stop = value; break;
         case BSSM_OPT_FUSE_STEP: c->opt_fuse_step = value; break;
+        case BSSM_OPT_RENORMALIZE: c->opt_renormalize = value ? 1 : 0; break;
         default: ARGFAIL("bssm_ctx_set_option: unknown option");
     }
     return BSSM_OK;
@@ -300,6 +303,8 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     const int Bg = c->sh_nloc ? B : 0;                                   // global block count handed to the kernels when sharded
     FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
     f.lead = boff; f.pub = c->sh_nloc ? boff + G / 2 : B / 2;
+    const bool fold = r.d_lw && !c->opt_renormalize && !c->sh_nloc && r.kind != BSSM_MULTINOMIAL_R;
+    f.fold = fold ? 1 : 0;
     f.gmax = (r.d_lw && !c->sh_nloc) ? c->gmax_cur : nullptr;       // (sharded: the partial maxima of other ranks are not in this rank's slots)
     f.ain_out = c->ain_w; f.plan = r.plan; f.N = r.nw; f.obs_i = r.obs_i; f.resample_algorithm = r.resample_algorithm;
     f.threshold = r.threshold; f.ess_out = r.d_ess; f.llh_out = r.d_llh; f.resampled_out = r.d_resampled;
@@ -322,17 +327,20 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     const bool inres = c->opt_inkernel_resolve && B <= 2 * NT;
     if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
     else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
-    if (inres) {
+    if (fold) {
+        // the W records are the records of cumsum(prob) (total == 1): the expansion resolves them directly
+        if (!inres) LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
+    } else if (inres) {
         LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p, boff, Bg);
     } else {
         LAUNCH(c, "k_resolve<W>", k_resolve<MODE_W>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
         LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), G, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec_p, c->side_p, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
         LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec_p, c->side_p, c->cin, c->ain_w, c->ain_p, c->st);
     }
-    const BlockRec* pb = inres ? c->brec_p : nullptr;
-    const SideList* psd = inres ? c->side_p : nullptr;
+    const BlockRec* pb = inres ? (fold ? c->brec : c->brec_p) : nullptr;
+    const SideList* psd = inres ? (fold ? c->side : c->side_p) : nullptr;
     ApplyArgs a;
-    a.w = r.d_w; a.nw = r.nw; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = r.n;
+    a.w = r.d_w; a.nw = r.nw; a.ain_p = fold ? c->ain_w : c->ain_p; a.cin = c->cin; a.lim = lim; a.n = r.n;
     a.u_base = r.d_u; a.u_stride = r.u_stride; a.key = r.key;
     a.anc_out = r.d_anc; a.anc_stride = r.anc_stride;
     a.cum_out = (r.kind == BSSM_MULTINOMIAL) ? (r.d_cum ? r.d_cum : c->cum) : r.d_cum;
@@ -916,7 +924,7 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
         // (1) the log-sum-exp partials of every block
         if ((rc = gather_blocks(c->pm, 8)) || (rc = gather_blocks(c->ps, 8)) || (rc = gather_blocks(c->pq, 8))) return rc;
         double* se_row = separt + (size_t)i * B;
-        FromLw f; f.lw = c->lw; f.w_out = c->w; f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B; f.gmax = nullptr;
+        FromLw f; f.lw = c->lw; f.w_out = c->w; f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B; f.gmax = nullptr; f.fold = 0;
         f.lead = boff; f.pub = boff + nloc / 2; f.ain_out = c->ain_w; f.plan = PLAN_PF; f.N = N; f.obs_i = i;
         f.resample_algorithm = resample_algorithm; f.threshold = threshold;
         f.ess_out = (double*)d_ess; f.llh_out = (double*)d_llh; f.resampled_out = (int*)d_resampled;
@@ -1072,7 +1080,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
     BatchArgs g;
     g.N = (int)N; g.T = T; g.resample_algorithm = resample_algorithm; g.resample_fn = cfg->resample_fn;
     g.lim = c->opt_window > 0 ? c->opt_window : rec_window(N);
-    g.lit_max = c->opt_batch_lit_max; g.move_sd = cfg->move_sd;
+    g.lit_max = c->opt_batch_lit_max; g.move_sd = cfg->move_sd; g.fold = c->opt_renormalize ? 0 : 1;
     g.threshold = threshold; g.y = (const double*)d_y; g.obs_times = (const int*)d_ot; g.lgy = (const double*)d_lgy;
     g.theta = (const double*)d_th; g.theta_stride = nth; g.log_sy = (const double*)d_lsy; g.keys = (const PhiloxKey*)d_keys;
     g.loglike = (double*)d_ll; g.state_est = (double*)d_se; g.ess = (double*)d_ess; g.llh = (double*)d_llh;

@@ -1017,6 +1017,9 @@ struct NoResolve { static constexpr bool active = false; __device__ __forceinlin
 struct FromLw {
     const double* lw; double* w_out; const double* pm; const double* ps; const double* pq; int nb;
     const unsigned long long* gmax;      // key of max(pm[0..nb)) left by the step kernel's atomics, or nullptr (then reduced here)
+    int fold;                            // 1: the resampler's own normalisation (prob = w / sum(w), src/resampling.cpp:24,51) is folded into
+                                         // this kernel's  w = exp(lw - max) / sum: total is taken as 1 and this pass's records ARE the
+                                         // records of cumsum(prob) -- no exact total, no second local pass
     int lead, pub;                       // the block that records the per-observation scalars (0) / publishes the prefixes (nblk / 2);
                                          // other values only when a filter's blocks are sharded over ranks (every rank keeps its own run state)
     double* ain_out;
@@ -1144,8 +1147,9 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
                 if (f.resampled_out) f.resampled_out[f.obs_i - 1] = doit;
                 st->ess = ess; st->lse_max = M; st->lse_sum = S;
                 if (doit) { st->cur_call = st->res_calls; st->res_calls += 1; }
+                if (f.fold) st->total_bits = d2b(1.0);
             }
-        } else if (bidx == f.lead && t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
+        } else if (bidx == f.lead && t == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; if (f.fold) st->total_bits = d2b(1.0); }
         if (t == bidx / L) {                      // the one lane whose slice holds this block: one division
             double pp = pre;
 #pragma unroll
@@ -2429,6 +2433,7 @@ __global__ void k_dump_uniforms(PhiloxKey key, uint32_t call, long long n, doubl
 // ---------------------------------------------------------------------------
 struct BatchArgs {
     int N, T, resample_algorithm, resample_fn, lim;
+    int fold;                                         // FromLw::fold
     int lit_max;                                      // N <= lit_max: exact sums by the in-order pass (block_literal_terms)
     double move_sd;                                   // resample-move: sd of the random-walk Metropolis proposal
     double threshold;
@@ -2623,14 +2628,14 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             step_emul<MODEL, false, 2>(sh16, xa, AUXLW, nullptr, N, par, yi, ns, &pm1, &ps1, &pq1);
             __syncthreads();
             FromLw fa;
-            fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.gmax = nullptr; fa.lead = 0; fa.pub = 0; fa.ain_out = &ainw1;
+            fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.gmax = nullptr; fa.fold = g.fold; fa.lead = 0; fa.pub = 0; fa.ain_out = &ainw1;
             fa.plan = PLAN_AUX; fa.N = N; fa.obs_i = i; fa.resample_algorithm = g.resample_algorithm; fa.threshold = g.threshold;
             fa.ess_out = nullptr; fa.llh_out = nullptr; fa.resampled_out = nullptr;
             if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa);
             else local_block<MODE_W, true, NT, false>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa);
             __syncthreads();
             if (t == 0 && !st.dead && !st.flags && st.do_resample) {
-                const uint64_t fs = br.prefix.o[0];
+                const uint64_t fs = g.fold ? d2b(1.0) : br.prefix.o[0];
                 const double tot = b2d(fs);
                 st.total_bits = fs;
                 if (tot == 0.0) st.flags |= FLAG_ZERO_SUM;
@@ -2666,7 +2671,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         }
         if (t == 0) { sep[0] = 0.0; sep[1] = 0.0; }
         FromLw fl;
-        fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.gmax = nullptr; fl.lead = 0; fl.pub = 0; fl.ain_out = &ainw1;
+        fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.gmax = nullptr; fl.fold = g.fold; fl.lead = 0; fl.pub = 0; fl.ain_out = &ainw1;
         fl.plan = PLAN_PF; fl.N = N; fl.obs_i = i; fl.resample_algorithm = g.resample_algorithm; fl.threshold = g.threshold;
         fl.ess_out = g.ess + (long long)fi * (T + 1); fl.llh_out = g.llh + (long long)fi * T; fl.resampled_out = nullptr;
         // normalise + loglik/ESS/decision + the exact sum(weights) of the block (:204-218, src/resampling.cpp:20-24)
@@ -2675,7 +2680,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         __syncthreads();
         PH(1)
         if (t == 0 && !st.dead && !st.flags && st.do_resample) {      // what k_resolve<W> / k_resolve<P> come to for one block
-            const uint64_t fs = br.prefix.o[0];
+            const uint64_t fs = g.fold ? d2b(1.0) : br.prefix.o[0];
             const double tot = b2d(fs);
             st.total_bits = fs;
             if (tot == 0.0) st.flags |= FLAG_ZERO_SUM;

@@ -290,6 +290,20 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "whole sweep", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None}
 
+    if rank == 0 and not REHEARSE and not args.no_batch:
+        # throughput mode (option renormalize = 0): the resampler's second normalisation (a division by 1 +- 1e-14,
+        # src/resampling.cpp:24,51) folded away -> one exact pass per observation instead of two.  Same law, exact on its own
+        # inputs, but NOT the reference's ancestors bit for bit (tests/test_gpu_fold.py), so it is reported alongside, never as `value`.
+        ctx.set_option("renormalize", 0)
+        run(7000)
+        tm = [run(7001 + k) for k in range(3)]
+        ctx.set_option("renormalize", 1)
+        ms_t = float(np.mean([r["_extras"]["device_ms"] for r in tm]))
+        out["throughput_mode"] = {"option": "renormalize=0", "device_ms_per_run": ms_t, "us_per_observation": 1e3 * ms_t / T,
+                                  "particle_steps_per_s": float(N) * T / (1e-3 * ms_t),
+                                  "sweep_frac_of_hbm_peak": SWEEP_BYTES * N * T / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "loglike_last_run": tm[-1]["loglike"]}
+
     # ---- chain-parallel PMMH: one chain per GPU, ONE all_gather of theta_chain at the end (R/pmmh.R:511-535) ----
     if not args.no_pmmh:
         iters = max(2, args.pmmh_iters)
