@@ -30,8 +30,16 @@
 
 namespace bssm {
 
-constexpr int NT = 256;          // threads per workgroup (4 waves)
-constexpr int EL = 8;            // terms per thread in the scan kernels
+#ifndef BSSM_NT                  // build-time shape of a scan workgroup (make NT=.. EL=..): NT threads x EL terms = EB
+#define BSSM_NT 256
+#endif
+#ifndef BSSM_EL
+#define BSSM_EL 8
+#endif
+constexpr int NT = BSSM_NT;      // threads per workgroup (NWV waves)
+constexpr int EL = BSSM_EL;      // terms per thread in the scan kernels
+constexpr int NWV = NT / 64;
+static_assert(NT * EL == 2048 && (NT == 256 || NT == 512) , "a scan workgroup covers 2048 terms with 4 or 8 waves");
 constexpr int EB = NT * EL;      // 2048 terms per workgroup
 constexpr int MAXB = 2048;       // max scan workgroups  => N <= 2^22 per filter
 
@@ -147,6 +155,13 @@ __device__ __forceinline__ int64_t lane63_i64(int64_t b)
 // wave totals, valid in every lane
 __device__ __forceinline__ double wave_sum(double v) { return lane63_f64(wave_incl_sum(v)); }
 __device__ __forceinline__ double wave_max(double v) { return lane63_f64(wave_incl_max(v)); }
+// pairwise sum of NW per-wave partials: (p0 + p1) + (p2 + p3) for four waves
+template <int NW>
+__device__ __forceinline__ double tree_sum(const double* p)
+{
+    if constexpr (NW == 1) return p[0];
+    else return tree_sum<NW / 2>(p) + tree_sum<NW / 2>(p + NW / 2);
+}
 // result valid in every thread
 __device__ __forceinline__ double block_sum(double v, double* sh4)
 {
@@ -154,7 +169,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh4)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+    return tree_sum<NWV>(sh4);
 }
 __device__ __forceinline__ double block_max(double v, double* sh4)
 {
@@ -162,7 +177,10 @@ __device__ __forceinline__ double block_max(double v, double* sh4)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmax(fmax(sh4[0], sh4[1]), fmax(sh4[2], sh4[3]));
+    double m = sh4[0];
+#pragma unroll
+    for (int i = 1; i < NWV; i++) m = fmax(m, sh4[i]);
+    return m;
 }
 template <int NW>
 __device__ __forceinline__ double block_sum_n(double v, double* sh)
@@ -331,7 +349,7 @@ __device__ __forceinline__ void init_block(double* sh4, const int bidx, double* 
 __global__ __launch_bounds__(NT) void k_init(double* __restrict__ x, long long N, NoiseSrc ns,
                                              double* __restrict__ se_part /* [nblocks][dim] */, int model, ModelPar par, int boff)
 {
-    __shared__ double sh4[4];
+    __shared__ double sh4[NWV];
     init_block(sh4, (int)blockIdx.x + boff, x, N, ns, se_part, model, par);
 }
 
@@ -469,7 +487,7 @@ __global__ __launch_bounds__(NTS) void k_step_sir(const double* xin, double* xou
 // stand-alone resampler front end: validation (src/resampling.cpp:6,18,45) + block sums
 __global__ __launch_bounds__(NT) void k_bsum(const double* __restrict__ w, long long nw, double* __restrict__ bsum, DevState* st)
 {
-    __shared__ double sh4[4];
+    __shared__ double sh4[NWV];
     const long long base = (long long)blockIdx.x * EB;
     double s = 0.0;
     uint32_t f = 0;
@@ -494,7 +512,7 @@ __global__ __launch_bounds__(NT) void k_bsum(const double* __restrict__ w, long 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_plan(const double* __restrict__ bsum, int B, double* __restrict__ ain, DevState* st)
 {
-    __shared__ double sh4[4];
+    __shared__ double sh4[NWV];
     if (threadIdx.x == 0) { st->do_resample = 1; st->cur_call = st->res_calls; st->res_calls += 1; }
     double loc[MAXB / NT];
     double tsum = 0.0;
@@ -660,7 +678,7 @@ struct SegSmem {
     Pure bnd_excl[MAXBND]; Rec bnd_rec[MAXBND]; int bnd_lane[MAXBND]; uint64_t bnd_ent[MAXBND];
     double bnd_terms[MAXBND][EL];    // the terms of every boundary lane (so a literal re-run never chases global memory)
     uint64_t seg_start[MAXBND + 1];
-    long long red_min[4][2], red_max[4][2];
+    long long red_min[NWV][2], red_max[NWV][2];
     uint64_t seg1_base;
     uint64_t segbase[MAXBND + 1]; int smin[MAXBND + 1]; int smax[MAXBND + 1];
     int nb; int fail; int first_bnd; int big;
@@ -768,7 +786,7 @@ __device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, boo
 template <int NW>
 __device__ __forceinline__ Pure seg_excl_scan_tail(SegSmem& sm, const Pure& val, bool isb, int nent, int& ent_before, int& ent_total)
 {
-    static_assert(NW <= 4, "workgroups of up to four waves");
+    static_assert(NW <= 8, "workgroups of up to eight waves");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned long long bal = __ballot(isb);
     Pure v = val;
@@ -941,29 +959,35 @@ __device__ __attribute__((noinline)) void block_literal(uint64_t* tin /* LDS [NT
 // loop (src/resampling.cpp:20,25) -- and records every lane's incoming state.  For a few hundred terms this is faster
 // than the parallel record machinery, whose fixed latency (scan + boundary chain) is ~13k cycles per pass.
 // `terms`: the n terms in order (LDS), already published and synchronised by the caller.
-static_assert(EL == 8, "block_literal_terms unrolls 8 terms per lane");
 __device__ __forceinline__ void block_literal_terms(uint64_t* tin /* LDS [NT] */, const double* terms, int n)
 {
     const int t = threadIdx.x;
     const int nl = (n + EL - 1) / EL;                      // lanes that hold terms (terms[] is zero-padded to a multiple of EL by the caller)
     if (t == 0) {
         double c = 0.0;
-        // two lanes (16 terms) per trip, the next trip's terms loaded a whole trip ahead: the LDS latency (~130 cycles)
-        // hides under 16 dependent adds.  Reading one lane past the last is harmless (inside the EB-sized buffer; the
-        // values are added only when tt + 1 < nl).
+        // 16 terms (LPT lanes) per trip, the next trip's terms loaded a whole trip ahead: the LDS latency (~130 cycles)
+        // hides under 16 dependent adds.  Reading up to a trip past the last lane is harmless (inside the EB-sized buffer;
+        // a lane's values are added only when the lane holds terms).
+        constexpr int LPT = 16 / EL;
         const double2* p = reinterpret_cast<const double2*>(terms);
-        double2 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6], a7 = p[7];
-        for (int tt = 0; tt < nl; tt += 2) {
-            const int nx = (tt + 2 < nl) ? tt + 2 : tt;
+        double2 a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = p[k];
+        for (int tt = 0; tt < nl; tt += LPT) {
+            const int nx = (tt + LPT < nl) ? tt + LPT : tt;
             const double2* q = p + (EL / 2) * nx;
-            const double2 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3], b4 = q[4], b5 = q[5], b6 = q[6], b7 = q[7];
-            tin[tt] = d2b(c);
-            c = c + a0.x; c = c + a0.y; c = c + a1.x; c = c + a1.y; c = c + a2.x; c = c + a2.y; c = c + a3.x; c = c + a3.y;
-            if (tt + 1 < nl) {
-                tin[tt + 1] = d2b(c);
-                c = c + a4.x; c = c + a4.y; c = c + a5.x; c = c + a5.y; c = c + a6.x; c = c + a6.y; c = c + a7.x; c = c + a7.y;
+#pragma unroll
+            for (int k = 0; k < 8; k++) b[k] = q[k];
+#pragma unroll
+            for (int l = 0; l < LPT; l++) {
+                if (l == 0 || tt + l < nl) {
+                    tin[tt + l] = d2b(c);
+#pragma unroll
+                    for (int k = 0; k < EL / 2; k++) { c = c + a[l * (EL / 2) + k].x; c = c + a[l * (EL / 2) + k].y; }
+                }
             }
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = b[k];
         }
         tin[NT] = d2b(c);                                   // the block's outgoing state
     }
@@ -984,7 +1008,7 @@ __device__ __forceinline__ void block_minmax2(SegSmem& sm, long long mn[2], long
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         long long a = sm.red_min[0][s], b = sm.red_max[0][s];
-        for (int wv = 1; wv < 4; wv++) { a = sm.red_min[wv][s] < a ? sm.red_min[wv][s] : a; b = sm.red_max[wv][s] > b ? sm.red_max[wv][s] : b; }
+        for (int wv = 1; wv < NWV; wv++) { a = sm.red_min[wv][s] < a ? sm.red_min[wv][s] : a; b = sm.red_max[wv][s] > b ? sm.red_max[wv][s] : b; }
         mn[s] = a; mx[s] = b;
     }
 }
@@ -1132,8 +1156,8 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
             __syncthreads();
             pre = exc;
             for (int i = 0; i < wave; i++) pre += sm.sh4[i];
-            S = (sm.sh4[0] + sm.sh4[1]) + (sm.sh4[2] + sm.sh4[3]);
-            sq = (sm.sh4[8] + sm.sh4[9]) + (sm.sh4[10] + sm.sh4[11]);
+            S = tree_sum<NWV>(sm.sh4);
+            sq = tree_sum<NWV>(sm.sh4 + 8);
         }
         int doit = 1;
         if (f.plan == PLAN_PF) {
@@ -2265,7 +2289,7 @@ __global__ __launch_bounds__(NT) void k_gather_anc(const int* __restrict__ anc_b
                                                    double* __restrict__ xdst, int dim, long long xstride, const double* __restrict__ auxsrc,
                                                    double* __restrict__ auxdst, double* __restrict__ se_part, DevState* st)
 {
-    __shared__ double sh4[4];
+    __shared__ double sh4[NWV];
     if (st->dead || !st->do_resample || st->flags) return;
     const int* anc = anc_base + (long long)st->cur_call * anc_stride;
     const double invN = 1.0 / (double)n;
@@ -2292,7 +2316,7 @@ __global__ __launch_bounds__(NT) void k_gather_anc(const int* __restrict__ anc_b
 
 __global__ __launch_bounds__(NT) void k_multinomial(const double* __restrict__ cum, long long nw, int n, ApplyArgs a, DevState* st)
 {
-    __shared__ double sh4[4];
+    __shared__ double sh4[NWV];
     multinomial_block(sh4, (int)blockIdx.x, cum, nw, n, a, st);
 }
 
@@ -2335,7 +2359,7 @@ __global__ __launch_bounds__(NT) void k_move(double* __restrict__ x, long long N
                                              PhiloxKey key, uint32_t call, double* __restrict__ se_part,
                                              const DevState* __restrict__ st)
 {
-    __shared__ double sh4[4];
+    __shared__ double sh4[NWV];
     move_block<MODEL>(sh4, (int)blockIdx.x, x, N, par, y, move_sd, zmv, umv, key, call, se_part, st);
 }
 
@@ -2376,7 +2400,7 @@ __global__ __launch_bounds__(NT) void k_carry(const double* __restrict__ xsrc, d
                                               const double* __restrict__ w, long long N, int dim,
                                               double* __restrict__ se_part, const DevState* __restrict__ st, int boff)
 {
-    __shared__ double sh4[4];
+    __shared__ double sh4[NWV];
     carry_block(sh4, (int)blockIdx.x + boff, xsrc, xdst, w, N, dim, se_part, st);
 }
 
@@ -2385,7 +2409,7 @@ __global__ __launch_bounds__(NT) void k_carry(const double* __restrict__ xsrc, d
 __global__ __launch_bounds__(NT) void k_reduce_state_est(const double* __restrict__ se_part, int nblocks, int dim,
                                                          double* __restrict__ state_est)
 {
-    __shared__ double sh4[4];
+    __shared__ double sh4[NWV];
     const long long row = blockIdx.x;
     for (int d = 0; d < dim; d++) {
         double s = 0.0;
