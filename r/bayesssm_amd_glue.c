@@ -140,11 +140,33 @@ SEXP _bayesSSM_pf_run(SEXP model, SEXP theta, SEXP y, SEXP obs_times, SEXP N, SE
     return out;
 }
 
+/* closure models: the reference's closures stay R code; what .particle_filter_core does with their log-weights
+ * (R/particle_filter_core.R:189-212: the all(lw < -1e8) guard, max / exp / sum, the log-likelihood increment, the ESS) is one call:
+ *   .Call("_bayesSSM_pf_weigh", log_weights)  ->  list(weights, increment, ess, degenerate)
+ * The resample decision (:214-218) and the resample_fn call (:220-224 -> the three entry points above, which draw from R's
+ * generator only when they are called, as in the reference) stay in R. */
+SEXP _bayesSSM_pf_weigh(SEXP lw)
+{
+    const long long n = (long long)XLENGTH(lw);
+    SEXP w = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)n));
+    double sc[4] = {0, 0, 0, 0};
+    int fl[2] = {0, 0};
+    const int st = bssm_pf_weigh_resample(get_ctx(n, 1), n, REAL(lw), /* always */ 0, BSSM_SIS, R_NaN, BSSM_STRATIFIED,
+                                          NULL, 0ull, 0ull, 0, REAL(w), NULL, sc, fl);
+    if (st != BSSM_OK) { UNPROTECT(1); check(st); }
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 4));
+    SET_VECTOR_ELT(out, 0, w); SET_VECTOR_ELT(out, 1, Rf_ScalarReal(sc[0]));
+    SET_VECTOR_ELT(out, 2, Rf_ScalarReal(sc[1])); SET_VECTOR_ELT(out, 3, Rf_ScalarLogical(fl[1]));
+    UNPROTECT(2);
+    return out;
+}
+
 static const R_CallMethodDef CallEntries[] = {     /* src/RcppExports.cpp:50-55: the three original names, arity 2 */
     {"_bayesSSM_resample_multinomial_cpp", (DL_FUNC)&_bayesSSM_resample_multinomial_cpp, 2},
     {"_bayesSSM_resample_stratified_cpp",  (DL_FUNC)&_bayesSSM_resample_stratified_cpp, 2},
     {"_bayesSSM_resample_systematic_cpp",  (DL_FUNC)&_bayesSSM_resample_systematic_cpp, 2},
     {"_bayesSSM_pf_run",                   (DL_FUNC)&_bayesSSM_pf_run, 11},
+    {"_bayesSSM_pf_weigh",                 (DL_FUNC)&_bayesSSM_pf_weigh, 1},
     {NULL, NULL, 0}
 };
 
