@@ -131,3 +131,33 @@ def test_chain_with_the_oracles_own_filter(B, ctx, oracle):
     np.testing.assert_allclose(dev["loglike_chain"], ref["loglike_chain"], rtol=1e-6)
     np.testing.assert_allclose(dev["theta_chain"], ref["theta_chain"], rtol=1e-12)
     assert dev["accepted"] == ref["accepted"]
+
+
+def test_c3_chain_at_full_size_with_the_oracles_own_filter(B, oracle):
+    """BASELINE C3's shape: the chain loop over C2's filter at its own size (N = 2^20, T = 1000, SISR + systematic), three
+    iterations, against the oracle's loop over the ORACLE's filter on the dump of each iteration's generator stream (25 s of
+    CPU per filter run).  Log-likelihoods to 1e-6 relative (measured: equal to 1e-15), the same accept / reject decisions,
+    the same theta rows."""
+    from bayesssm_amd.pmmh import run_chain_device, chain_draws
+    from bench import simulate_lg
+    N, T, m_it, seed, ci = 1 << 20, 1000, 3, 1405, 0
+    ys = simulate_lg(T)
+    cx = B.Context(0, N, 1)
+    kinds = [("normal", 0.0, 1.0), ("exponential", 1.0, 0.0), ("exponential", 1.0, 0.0)]
+    cov = np.diag([1e-4, 1e-4, 1e-4])
+    tr = ["identity", "log", "log"]
+    d = chain_draws(seed, ci, m_it, 3)
+
+    def cpu_pf(th, it):
+        dr = B.dump_draws("BPF", T, N, "systematic", seed, (ci << 32) | it, ctx=cx)
+        return oracle.pf_run("lg", th, ys, N, dr["z_init"], dr["z_trans"], dr["u_res"], resample_algorithm="SISR",
+                             resample_fn="systematic")["loglike"]
+
+    dev = run_chain_device(pf_wrapper=B.bootstrap_filter, y=ys, m=m_it, model="lg", n_params=3, init_theta=[0.8, 1.0, 1.0],
+                           proposal_cov=cov, transform=tr, priors=_priors(B, kinds), num_particles=N, seed=seed, chain_index=ci,
+                           resample_algorithm="SISR", resample_fn="systematic", ctx=cx)
+    ref = oracle.pmmh_chain(cpu_pf, m_it, [0.8, 1.0, 1.0], cov, tr, kinds, d["z_prop"], d["u_accept"])
+    cx.close()
+    np.testing.assert_allclose(dev["loglike_chain"], ref["loglike_chain"], rtol=1e-6)
+    np.testing.assert_allclose(dev["theta_chain"], ref["theta_chain"], rtol=1e-12)
+    assert dev["accepted"] == ref["accepted"]
