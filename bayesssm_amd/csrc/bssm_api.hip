@@ -137,7 +137,9 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
     c->device = device; c->cap = max_particles; c->max_dim = max_dim; c->maxB = (int)B;
     const size_t npad = (size_t)B * EB;
     hipError_t e = hipSuccess;
-    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); } };
+    // zero-fill ON THE CONTEXT'S STREAM: the stream is non-blocking, so a hipMemset on the null stream is not ordered with the
+    // context's first kernels and could land after them (seen once as wrong weights in the first call of a fresh 2^20 context)
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, c->stream); } };
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     A((void**)&c->x0, npad * 8 * max_dim); A((void**)&c->x1, npad * 8 * max_dim);
     A((void**)&c->lw, npad * 8); A((void**)&c->w, npad * 8); A((void**)&c->auxlw, npad * 8); A((void**)&c->auxg, npad * 8);
@@ -147,6 +149,7 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
     A((void**)&c->brec, MAXB * sizeof(BlockRec)); A((void**)&c->brec_p, MAXB * sizeof(BlockRec)); A((void**)&c->cin, MAXB * 8);
     A((void**)&c->side, (size_t)B * sizeof(SideList)); A((void**)&c->side_p, (size_t)B * sizeof(SideList));
     A((void**)&c->st, sizeof(DevState));
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resolve<MODE_W>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXB * (int)sizeof(BlockRec));

@@ -40,6 +40,9 @@ def test_weigh_resample_both_modes_exact_on_their_inputs(B, oracle, N, rf):
         out[rn] = _weigh_resample(ctx, lw, True, "SISR", None, rf, u)
     ctx.close()
     w1, w0 = out[1]["weights"], out[0]["weights"]
+    e = np.exp(lw - lw.max())
+    for rn in (1, 0):
+        np.testing.assert_allclose(out[rn]["weights"], e / e.sum(), rtol=1e-12, err_msg="renormalize=%d" % rn)
     assert (w1 == w0).all() and out[1]["increment"] == out[0]["increment"] and out[1]["ess"] == out[0]["ess"]
     # renormalize = 1: the stand-alone resampler (total = sum(w) in order, prob = w / total) on the filter's weights, bit for bit
     ref = (oracle.resample_systematic(N, w1, u[0]) if rf == "systematic" else oracle.resample_stratified(N, w1, u))
