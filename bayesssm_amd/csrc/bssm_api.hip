@@ -330,9 +330,17 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     const bool inres = c->opt_inkernel_resolve && B <= 2 * NT;
     if (r.d_lw) LAUNCH(c, "k_weights(normalize+local<W>)", (k_local<MODE_W, true>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
     else LAUNCH(c, "k_local<W>", (k_local<MODE_W, false>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec, c->side, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
+    // grids of more than 2 NT blocks: one workgroup of NTR threads runs the block-wide resolve and emits every block's state
+    // (k_resolve_all); k_resolve (the round-1 resolver) remains for inkernel_resolve = 0 on small grids
+    const bool rall = c->opt_inkernel_resolve && !inres && B <= 2 * NTR;
     if (fold) {
         // the W records are the records of cumsum(prob) (total == 1): the expansion resolves them directly
-        if (!inres) LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
+        if (rall) LAUNCH(c, "k_resolve_all<P>", k_resolve_all<MODE_P>, 1, NTR, 0, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
+        else if (!inres) LAUNCH(c, "k_resolve<P>", k_resolve<MODE_P>, 1, NTR, shm, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
+    } else if (rall) {
+        LAUNCH(c, "k_resolve_all<W>", k_resolve_all<MODE_W>, 1, NTR, 0, r.d_w, r.nw, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
+        LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), G, NT, 0, r.d_w, r.nw, c->ain_p, lim, c->brec_p, c->side_p, c->st, f, nullptr, nullptr, nullptr, boff, Bg);
+        LAUNCH(c, "k_resolve_all<P>", k_resolve_all<MODE_P>, 1, NTR, 0, r.d_w, r.nw, B, c->brec_p, c->side_p, c->cin, c->ain_w, c->ain_p, c->st);
     } else if (inres) {
         LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), G, NT, 0, r.d_w, r.nw, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p, boff, Bg);
     } else {

@@ -786,7 +786,7 @@ __device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, boo
 template <int NW>
 __device__ __forceinline__ Pure seg_excl_scan_tail(SegSmem& sm, const Pure& val, bool isb, int nent, int& ent_before, int& ent_total)
 {
-    static_assert(NW <= 8, "workgroups of up to eight waves");
+    static_assert(NW <= 16, "workgroups of up to sixteen waves");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned long long bal = __ballot(isb);
     Pure v = val;
@@ -1453,19 +1453,21 @@ __device__ __forceinline__ bool run_ok(const LaneRun& r, uint64_t ent)
     return diff >= r.wlo && diff <= r.whi;
 }
 
-template <int MODE>
+// NTX: threads of the calling workgroup (NT inside the scan kernels; NTR in k_resolve_all, which also EMITs every block's
+// exact incoming state to cin_out).
+template <int MODE, int NTX = NT, bool EMIT = false>
 __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& rs, const BlockRec* __restrict__ brec,
                                                      const SideList* __restrict__ side, const int B, const int upto,
                                                      const double* __restrict__ w, long long nw, double total, DevState* st,
-                                                     const bool count_stats)
+                                                     const bool count_stats, uint64_t* __restrict__ cin_out = nullptr)
 {
     const int t = threadIdx.x;
     if (upto <= 0) return 0ull;                        // (block-uniform)
     const int dbg = st->debug_stop; (void)dbg;
-    const bool stamper = (t == 0 && blockIdx.x == 100); (void)stamper;
+    const bool stamper = (t == 0 && (EMIT || blockIdx.x == 100)); (void)stamper;
     BSSM_STAMP(st, dbg, MODE, 0, stamper);
     // ---- all threads: thread t holds CB (1 or 2) consecutive blocks, straight from global memory into registers ----
-    const int CB = (B + NT - 1) / NT;                  // (the caller guarantees B <= 2 NT)
+    const int CB = (B + NTX - 1) / NTX;                // (the caller guarantees B <= 2 NTX)
     const int c0 = t * CB, c1 = (c0 + CB < upto) ? c0 + CB : upto;
     BlockRec r0, r1;
     r0.prefix = rec_identity(0); r0.tail_from = NT; r0.nside = 0; r1 = r0;
@@ -1474,8 +1476,8 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     if (t == 0) { rs.sout[0] = 0; rs.fail = 0; }
     // the last block of a full pass nearly always carries one side entry (the lanes next to cum == 1.0 are never PURE):
     // fetch it now, with the records, so that the walk does not wait for a dependent global load later
-    if (upto == B && t >= NT - (int)(sizeof(SideEntry) / 16)) {
-        const int q = t - (NT - (int)(sizeof(SideEntry) / 16));
+    if (upto == B && t >= NTX - (int)(sizeof(SideEntry) / 16)) {
+        const int q = t - (NTX - (int)(sizeof(SideEntry) / 16));
         reinterpret_cast<uint4*>(&rs.sideC[63])[q] = reinterpret_cast<const uint4*>(&side[upto - 1].e[0])[q];
     }
     // head = the PURE run in front of the thread's first non-PURE block, tail = the run behind its last one
@@ -1488,7 +1490,7 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     if (c0 + 1 < c1 && !x1) { if (x0) run_fold(tail, r1.prefix); else run_fold(head, r1.prefix); }
     const int nent = (x0 ? 1 : 0) + (x1 ? 1 : 0);
     int ent_before, E;
-    const Pure carry = seg_excl_scan_tail<NT / 64>(sm, nent ? tail.p : head.p, nent > 0, nent, ent_before, E);
+    const Pure carry = seg_excl_scan_tail<NTX / 64>(sm, nent ? tail.p : head.p, nent > 0, nent, ent_before, E);
     const bool fits = (E <= 64);
     // the links: every non-PURE block with the PURE run in front of it
     if (fits && nent) {
@@ -1576,13 +1578,22 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
         }
         if (!ok) rs.fail = 1;
         if (c1 == upto) rs.result = end;                                 // this thread holds the last block of the range
+        if constexpr (EMIT) {
+            // every block's exact incoming state: the thread's first block enters at `ent`; its second one behind the first
+            // block's link (non-PURE) or behind the first block's own PURE record
+            cin_out[c0] = ent;
+            if (c0 + 1 < c1) {
+                LaneRun h0; run_reset(h0); run_fold(h0, r0.prefix);
+                cin_out[c0 + 1] = x0 ? rs.sout[ent_before + 1] : pure_step(h0.p, ent);
+            }
+        }
     }
     __syncthreads();
     if (rs.fail) {
         // the records did not cover the exact states: one lane walks every block (each step is still exact)
         if (t == 0) {
             uint64_t sf = 0;
-            for (int b = 0; b < upto; b++) { const BlockRec r = brec[b]; sf = block_out_exact<MODE>(r, side, w, nw, total, b, sf, lit); }
+            for (int b = 0; b < upto; b++) { const BlockRec r = brec[b]; if (EMIT) cin_out[b] = sf; sf = block_out_exact<MODE>(r, side, w, nw, total, b, sf, lit); }
             rs.result = sf;
             if (count_stats) atomicAdd((unsigned long long*)&st->stat_serial_walks, 1ull);
         }
@@ -1816,6 +1827,34 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
         const double tot = b2d(final_state);
         if (t == 0) {
             st->total_bits = final_state;
+            if (tot == 0.0) atomicOr(&st->flags, FLAG_ZERO_SUM);       // src/resampling.cpp:8,22,49
+            if (!isfinite(tot)) atomicOr(&st->flags, FLAG_NONFINITE);
+        }
+        for (int b = t; b < B; b += NTR) ain_p[b] = ain_w[b] / tot;
+    }
+}
+
+// k_resolve_all: grids of more than 2 NT blocks (N > 2^20): ONE workgroup of NTR threads runs the same block-wide resolve
+// as the scan kernels do for themselves (resolve_in_block: records straight into registers, one segmented scan, the links in
+// registers) and emits every block's exact incoming state.  Replaces k_resolve there (19 -> see DESIGN.md us at 2048 blocks).
+template <int MODE>
+__global__ __launch_bounds__(NTR) void k_resolve_all(const double* __restrict__ w, long long nw, int B,
+                                                     const BlockRec* __restrict__ brec, const SideList* __restrict__ side,
+                                                     uint64_t* __restrict__ cin,
+                                                     const double* __restrict__ ain_w, double* __restrict__ ain_p, DevState* st)
+{
+    __shared__ SegSmem sm;
+    __shared__ ResolveSmem rs;
+    const int t = threadIdx.x;
+    const int s_dead = st->dead, s_do = st->do_resample;
+    const uint32_t s_flags = st->flags;
+    const double total = (MODE == MODE_P) ? b2d(st->total_bits) : 1.0;
+    if (s_dead || s_flags || !s_do) return;
+    const uint64_t fin = resolve_in_block<MODE, NTR, true>(sm, rs, brec, side, B, B, w, nw, total, st, true, cin);
+    if (MODE == MODE_W) {
+        const double tot = b2d(fin);
+        if (t == 0) {
+            st->total_bits = fin;
             if (tot == 0.0) atomicOr(&st->flags, FLAG_ZERO_SUM);       // src/resampling.cpp:8,22,49
             if (!isfinite(tot)) atomicOr(&st->flags, FLAG_NONFINITE);
         }

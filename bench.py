@@ -50,6 +50,8 @@ KERNEL_BYTES = {
     "k_apply+step<stratified>": 32.0,
     "k_resolve<W>": 64.0 / 2048,                # B block records of 64 B
     "k_resolve<P>": 64.0 / 2048,
+    "k_resolve_all<W>": 64.0 / 2048,
+    "k_resolve_all<P>": 64.0 / 2048,
 }
 REHEARSE = os.environ.get("BENCH_REHEARSE", "0") == "1"      # CPU rehearsal of the control flow (tests/): filter runs are stubs
 

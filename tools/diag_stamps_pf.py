@@ -5,13 +5,13 @@ import numpy as np, bayesssm_amd as b
 from bayesssm_amd import _lib
 from bench import simulate_lg
 lib = _lib.load()
-N = 1 << 20
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 ctx = b.Context(0, N, 1)
 ys = simulate_lg(1000)[:30]
 m = b.models.linear_gaussian()
 ctx.set_option('debug_stop', 99)
 r = b.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm="SISR",
-                       resample_fn="systematic", return_particles=False, seed=1, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
+                       resample_fn=(sys.argv[2] if len(sys.argv) > 2 else "systematic"), return_particles=False, seed=1, ctx=ctx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
 st = np.zeros((4, 16), dtype=np.int64)
 lib.bssm_ctx_get_stamps(ctx.handle, st.ctypes.data_as(C.c_void_p))
 for r in (0, 1): print('resolve', r, 'walk setup->loop start', st[r][10] - st[r][4], 'loop', st[r][11] - st[r][10], 'after loop -> walk end', st[r][5] - st[r][11], 'chain took', st[r][12], 'links in', st[r][13] - st[r][10])
