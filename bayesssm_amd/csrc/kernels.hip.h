@@ -1244,13 +1244,16 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         return;
     }
     // validity windows of segment 0 (lanes before the first boundary) and of the last segment when nb == 1
-    if (t == 0) sm.first_bnd = NT;
-    __syncthreads();
-    if (bs.isb && bs.seg == 0) sm.first_bnd = t;
-    __syncthreads();
-    const int fb = sm.first_bnd;
-    if (bs.nb >= 1 && t == fb + 1) sm.seg1_base = bs.leaf.base;
-    __syncthreads();
+    int fb = NT;
+    if (bs.nb > 0) {                       // (block-uniform; the typical block has no boundary lane and skips three barriers)
+        if (t == 0) sm.first_bnd = NT;
+        __syncthreads();
+        if (bs.isb && bs.seg == 0) sm.first_bnd = t;
+        __syncthreads();
+        fb = sm.first_bnd;
+        if (t == fb + 1) sm.seg1_base = bs.leaf.base;
+        __syncthreads();
+    }
     long long mn[2] = {(1ll << 40), (1ll << 40)}, mx[2] = {-(1ll << 40), -(1ll << 40)};
     if (!bs.isb && bs.seg <= 1) {
         const uint64_t sb = (bs.seg == 0) ? hb0 : (sm.seg1_base & ~3ull);
