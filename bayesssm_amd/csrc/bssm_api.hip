@@ -945,9 +945,11 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
         if (h.dead || h.flags) break;                                                     // identical on every rank: all leave together
         if (h.do_resample) {
             // (2) the records of sum(w), (3) the records of cumsum(w / total): every rank resolves them itself
-            if ((rc = gather_blocks(c->brec, sizeof(BlockRec))) || (rc = gather_blocks(c->side, sizeof(SideList)))) return rc;
+            for (int q = 0; q < 4; q++) if ((rc = gather_blocks((char*)c->brec + (size_t)q * BREC_STRIDE * 16, 16))) return rc;      // (the records live in four planes)
+            if ((rc = gather_blocks(c->side, sizeof(SideList)))) return rc;
             LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), nloc, NT, 0, c->w, N, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p, boff, B);
-            if ((rc = gather_blocks(c->brec_p, sizeof(BlockRec))) || (rc = gather_blocks(c->side_p, sizeof(SideList)))) return rc;
+            for (int q = 0; q < 4; q++) if ((rc = gather_blocks((char*)c->brec_p + (size_t)q * BREC_STRIDE * 16, 16))) return rc;
+            if ((rc = gather_blocks(c->side_p, sizeof(SideList)))) return rc;
             ApplyArgs a;
             a.w = c->w; a.nw = N; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = (int)N;
             a.u_base = (const double*)d_ur; a.u_stride = u_stride; a.key = key; a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr;

@@ -60,6 +60,28 @@ struct BlockRec { Rec prefix; int32_t tail_from; int32_t nside; };   // 64 bytes
 constexpr int MAXBND = 64;       // boundaries handled per block before the literal fallback
 struct SideEntry { Rec leaf; int64_t d0, d1; uint64_t post_base; int32_t lo, hi; int32_t lane; int32_t pad; double terms[EL]; };  // 160 bytes
 struct SideList { SideEntry e[MAXBND]; };
+// Block records live in HBM as FOUR PLANES of 16-byte pieces (piece q of block b at plane q, index b; plane stride
+// BREC_STRIDE blocks): the grid-level resolve has thread t fetch the records of blocks 2t, 2t+1, and with whole 64-byte
+// records side by side every lane of such a load touched its own cache line (512 tag look-ups per wave for 8 KiB); by
+// planes a wave's load covers 2 KiB contiguously.  `stride` 1 = one record on its own (the batched kernel's local record).
+constexpr int BREC_STRIDE = MAXB;
+static_assert(sizeof(BlockRec) == 64, "four 16-byte pieces");
+__device__ __forceinline__ void store_brec(BlockRec* __restrict__ base, int b, const BlockRec& r, int stride = BREC_STRIDE)
+{
+    uint4* u = reinterpret_cast<uint4*>(base);
+    const uint4* q = reinterpret_cast<const uint4*>(&r);
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[(size_t)k * stride + b] = q[k];
+}
+__device__ __forceinline__ BlockRec load_brec(const BlockRec* __restrict__ base, int b, int stride = BREC_STRIDE)
+{
+    BlockRec r;
+    const uint4* u = reinterpret_cast<const uint4*>(base);
+    uint4* q = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = u[(size_t)k * stride + b];
+    return r;
+}
 
 // Per-run scalars living in HBM; written by single-workgroup kernels, read by all.
 struct DevState {
@@ -1060,7 +1082,8 @@ template <int MODE, bool FROM_LW, int MAXBL, bool LIT = false, class Pro = NoRes
 __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, double* es /* [MAXBL], FROM_LW only */, const int bidx, const int nblk,
                                             const double* __restrict__ w, long long nw, const double* __restrict__ ain,
                                             int lim, BlockRec* __restrict__ brec, SideList* __restrict__ side, DevState* st,
-                                            const FromLw& f, const Pro pro = Pro(), double* __restrict__ ain_p_out = nullptr)
+                                            const FromLw& f, const Pro pro = Pro(), double* __restrict__ ain_p_out = nullptr,
+                                            const int bstride = BREC_STRIDE)
 {
     const int t = threadIdx.x;
     const long long b0 = (long long)bidx * EB;
@@ -1221,7 +1244,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         // one block of few terms, incoming state +0 (FROM_LW: the terms are already in f.w_out, in order, zero beyond nw)
         __syncthreads();
         block_literal_terms(tin, FROM_LW ? f.w_out : w, (int)nw);
-        if (t == NT - 1) { BlockRec br; br.prefix = rec_abs(tin[NT]); br.tail_from = NT; br.nside = 0; brec[bidx] = br; }
+        if (t == NT - 1) { BlockRec br; br.prefix = rec_abs(tin[NT]); br.tail_from = NT; br.nside = 0; store_brec(brec, bidx, br, bstride); }
         return;
     }
     BlockScan bs;
@@ -1239,7 +1262,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
 #pragma unroll
             for (int k = 0; k < EL; k++) c = c + v[k];
             BlockRec br; br.prefix = rec_abs(d2b(c)); br.tail_from = NT; br.nside = 0;
-            brec[bidx] = br;
+            store_brec(brec, bidx, br, bstride);
         }
         return;
     }
@@ -1268,7 +1291,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
     if (bs.nb == 0) {
         if (t == NT - 1) {
             BlockRec br; br.prefix = pure_to_rec(bs.last_seg, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
-            br.tail_from = NT; br.nside = 0; brec[bidx] = br;
+            br.tail_from = NT; br.nside = 0; store_brec(brec, bidx, br, bstride);
         }
         return;
     }
@@ -1283,13 +1306,13 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
                 const Rec post = pure_to_rec(bs.last_seg, sm.seg1_base, -(long long)lim - mn[1] + 4, (long long)lim - mx[1] - 4);
                 r = rec_compose(r, post);
             }
-            if (r.kind != REC_HARD) { br.prefix = r; br.tail_from = NT; br.nside = 0; brec[bidx] = br; done1 = true; }
+            if (r.kind != REC_HARD) { br.prefix = r; br.tail_from = NT; br.nside = 0; store_brec(brec, bidx, br, bstride); done1 = true; }
         }
         if (!done1) {
             br.prefix = pre;
             if (bs.nb <= MAXBND) { br.tail_from = NT; br.nside = bs.nb; }     // side list below
             else { br.tail_from = fb; br.nside = 0; }                          // too many: literal tail
-            brec[bidx] = br;
+            store_brec(brec, bidx, br, bstride);
             atomicAdd((unsigned long long*)&st->stat_hard_blocks, 1ull);
         }
         sm.fail = done1 ? 1 : 0;      // reuse as "record complete" flag for the block
@@ -1474,8 +1497,8 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     const int c0 = t * CB, c1 = (c0 + CB < upto) ? c0 + CB : upto;
     BlockRec r0, r1;
     r0.prefix = rec_identity(0); r0.tail_from = NT; r0.nside = 0; r1 = r0;
-    if (c0 < c1) r0 = brec[c0];
-    if (c0 + 1 < c1) r1 = brec[c0 + 1];
+    if (c0 < c1) r0 = load_brec(brec, c0);
+    if (c0 + 1 < c1) r1 = load_brec(brec, c0 + 1);
     if (t == 0) { rs.sout[0] = 0; rs.fail = 0; }
     // the last block of a full pass nearly always carries one side entry (the lanes next to cum == 1.0 are never PURE):
     // fetch it now, with the records, so that the walk does not wait for a dependent global load later
@@ -1596,7 +1619,7 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
         // the records did not cover the exact states: one lane walks every block (each step is still exact)
         if (t == 0) {
             uint64_t sf = 0;
-            for (int b = 0; b < upto; b++) { const BlockRec r = brec[b]; if (EMIT) cin_out[b] = sf; sf = block_out_exact<MODE>(r, side, w, nw, total, b, sf, lit); }
+            for (int b = 0; b < upto; b++) { const BlockRec r = load_brec(brec, b); if (EMIT) cin_out[b] = sf; sf = block_out_exact<MODE>(r, side, w, nw, total, b, sf, lit); }
             rs.result = sf;
             if (count_stats) atomicAdd((unsigned long long*)&st->stat_serial_walks, 1ull);
         }
@@ -1674,7 +1697,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
         const uint4* src = reinterpret_cast<const uint4*>(brec);
         uint4* dst = reinterpret_cast<uint4*>(smraw);
         const int n16 = B * (int)(sizeof(BlockRec) / 16);
-        for (int i = t; i < n16; i += NTR) dst[i] = src[i];
+        for (int i = t; i < n16; i += NTR) dst[i] = src[(size_t)(i & 3) * BREC_STRIDE + (i >> 2)];      // planes -> whole records
     }
     if (t == 0) sm.fail = 0;
     __syncthreads();
@@ -2697,8 +2720,8 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.gmax = nullptr; fa.fold = g.fold; fa.lead = 0; fa.pub = 0; fa.ain_out = &ainw1;
             fa.plan = PLAN_AUX; fa.N = N; fa.obs_i = i; fa.resample_algorithm = g.resample_algorithm; fa.threshold = g.threshold;
             fa.ess_out = nullptr; fa.llh_out = nullptr; fa.resampled_out = nullptr;
-            if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa);
-            else local_block<MODE_W, true, NT, false>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa);
+            if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa, NoResolve(), nullptr, 1);
+            else local_block<MODE_W, true, NT, false>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa, NoResolve(), nullptr, 1);
             __syncthreads();
             if (t == 0 && !st.dead && !st.flags && st.do_resample) {
                 const uint64_t fs = g.fold ? d2b(1.0) : br.prefix.o[0];
@@ -2741,8 +2764,8 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         fl.plan = PLAN_PF; fl.N = N; fl.obs_i = i; fl.resample_algorithm = g.resample_algorithm; fl.threshold = g.threshold;
         fl.ess_out = g.ess + (long long)fi * (T + 1); fl.llh_out = g.llh + (long long)fi * T; fl.resampled_out = nullptr;
         // normalise + loglik/ESS/decision + the exact sum(weights) of the block (:204-218, src/resampling.cpp:20-24)
-        if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fl);
-        else local_block<MODE_W, true, NT, false>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fl);
+        if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fl, NoResolve(), nullptr, 1);
+        else local_block<MODE_W, true, NT, false>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fl, NoResolve(), nullptr, 1);
         __syncthreads();
         PH(1)
         if (t == 0 && !st.dead && !st.flags && st.do_resample) {      // what k_resolve<W> / k_resolve<P> come to for one block
