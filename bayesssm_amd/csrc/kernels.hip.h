@@ -216,6 +216,19 @@ __device__ __forceinline__ double block_sum_n(double v, double* sh)
     for (int i = 0; i < NW; i++) s += sh[i];
     return s;
 }
+// two sums at once (one barrier pair instead of two); each is added in the same order as block_sum_n adds it.  sh: 2 NW doubles
+template <int NW>
+__device__ __forceinline__ void block_sum2_n(double& a, double& b, double* sh)
+{
+    a = wave_sum(a); b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = a; sh[NW + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) { s += sh[i]; q += sh[NW + i]; }
+    a = s; b = q;
+}
 template <int NW>
 __device__ __forceinline__ double block_max_n(double v, double* sh)
 {
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
     // (no early return on st->dead here: a dependent read of the run state in front of the particle loads would
     //  cost every launch a memory round trip; propagating a dead run is harmless, its results are never read)
     (void)st;
-    __shared__ double sh[NTS / 64];
+    __shared__ double sh[2 * (NTS / 64)];
     const long long j = (long long)bx * EB + 2 * (long long)threadIdx.x;
     double l0 = -INFINITY, l1 = -INFINITY;
     if (j < N) {
@@ -434,8 +447,7 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
             if (l0 > -INFINITY) { const double e = exp(l0 - bm); s += e; q += e * e; }
             if (l1 > -INFINITY) { const double e = exp(l1 - bm); s += e; q += e * e; }
         }
-        s = block_sum_n<NTS / 64>(s, sh);
-        q = block_sum_n<NTS / 64>(q, sh);
+        block_sum2_n<NTS / 64>(s, q, sh);
         // max(log_weights) over the whole grid (R/particle_filter_core.R:204) by one atomic per block: the next kernel reads
         // it with one load instead of reducing the B block maxima again in every workgroup
         if (threadIdx.x == 0) { pm[bx] = bm; ps[bx] = s; pq[bx] = q; if (gmax) atomicMax(gmax + (bx % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(NTS) void k_lw_partials(const double* __restrict__ 
                                                      double* __restrict__ ps, double* __restrict__ pq,
                                                      unsigned long long* __restrict__ gmax)
 {
-    __shared__ double sh[NTS / 64];
+    __shared__ double sh[2 * (NTS / 64)];
     const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
     double l0 = -INFINITY, l1 = -INFINITY;
     if (j < N) { l0 = lw[j]; if (j + 1 < N) l1 = lw[j + 1]; }
@@ -459,8 +471,7 @@ __global__ __launch_bounds__(NTS) void k_lw_partials(const double* __restrict__ 
         if (l0 > -INFINITY) { const double e = exp(l0 - bm); s += e; q += e * e; }
         if (l1 > -INFINITY) { const double e = exp(l1 - bm); s += e; q += e * e; }
     }
-    s = block_sum_n<NTS / 64>(s, sh);
-    q = block_sum_n<NTS / 64>(q, sh);
+    block_sum2_n<NTS / 64>(s, q, sh);
     if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; if (gmax) atomicMax(gmax + (blockIdx.x % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
 }
 
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(NTS) void k_step_sir(const double* xin, double* xou
                                                   double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq,
                                                   unsigned long long* __restrict__ gmax)
 {
-    __shared__ double sh[NTS / 64];
+    __shared__ double sh[2 * (NTS / 64)];
     const long long j = (long long)blockIdx.x * EB + 2 * (long long)threadIdx.x;
     double l0 = -INFINITY, l1 = -INFINITY;
     if (j < N) {
@@ -500,8 +511,7 @@ __global__ __launch_bounds__(NTS) void k_step_sir(const double* xin, double* xou
             if (l0 > -INFINITY) { const double e = exp(l0 - bm); s += e; q += e * e; }
             if (l1 > -INFINITY) { const double e = exp(l1 - bm); s += e; q += e * e; }
         }
-        s = block_sum_n<NTS / 64>(s, sh);
-        q = block_sum_n<NTS / 64>(q, sh);
+        block_sum2_n<NTS / 64>(s, q, sh);
         if (threadIdx.x == 0) { pm[blockIdx.x] = bm; ps[blockIdx.x] = s; pq[blockIdx.x] = q; atomicMax(gmax + (blockIdx.x % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
     }
 }
