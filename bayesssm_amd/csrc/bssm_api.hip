@@ -361,10 +361,15 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     a.lead = boff; a.last = boff + G - 1;
     a.step_model = r.step_model; a.step_par = r.step_par; a.step_y = r.step_y; a.step_ns = r.step_ns; a.step_lw = c->lw;
     a.nstage = (c->opt_stage && r.xdst && !r.d_anc && r.kind != BSSM_MULTINOMIAL) ? (r.dim > 1 ? 2 : 1) + (r.auxdst ? 1 : 0) : 0;
-    const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), inres ? sizeof(ResolveSmem) : (size_t)0);
     const bool step = r.step_model >= 0;
+    // several rounds of workgroups per CU (more than 2 NT blocks), scalar state, nothing else to carry: the lean expansion
+    // (fewer registers, a smaller staging area: four workgroups per CU instead of three)
+    const bool lean = !inres && !step && B > 2 * NT && r.dim == 1 && !r.auxdst && !r.d_anc && a.nstage == 1;
+    const size_t xshm = lean ? (size_t)CAP_LEAN * sizeof(double)
+                             : std::max((size_t)a.nstage * CAPX * sizeof(double), inres ? sizeof(ResolveSmem) : (size_t)0);
 #define APPLY(K, NAME) do { \
-        if (inres && step) LAUNCH(c, "k_apply+step<" NAME ">(+resolve<P>)", (k_apply<K, true, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); \
+        if (lean) LAUNCH(c, "k_apply<" NAME ",lean>", (k_apply<K, false, false, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); \
+        else if (inres && step) LAUNCH(c, "k_apply+step<" NAME ">(+resolve<P>)", (k_apply<K, true, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); \
         else if (inres) LAUNCH(c, "k_apply<" NAME ">(+resolve<P>)", (k_apply<K, true, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); \
         else if (step) LAUNCH(c, "k_apply+step<" NAME ">", (k_apply<K, false, true>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); \
         else LAUNCH(c, "k_apply<" NAME ">", (k_apply<K, false, false>), G, NT, xshm, a, c->st, pb, psd, boff, Bg); } while (0)

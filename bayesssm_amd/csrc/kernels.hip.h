@@ -1960,12 +1960,16 @@ __device__ __attribute__((noinline)) double2 expand_by_search(const int* Tl, int
 
 constexpr int CAPX = 3072;       // outputs a block can stage in LDS for the coalesced store (it owns ~EB of them)
 
-template <int KIND, bool LIT = false, class Pro = NoResolve, bool STEP = false>
+// LEAN (scalar state, no auxiliary log-weights to carry; grids that run several rounds of workgroups per CU): the registers of the
+// second state component and of the auxiliary values are not allocated, and CAP < CAPX outputs are staged -- together four
+// workgroups fit a CU instead of three (112 VGPRs, 40.7 KiB LDS).
+template <int KIND, bool LIT = false, class Pro = NoResolve, bool STEP = false, int CAP = CAPX, bool LEAN = false>
 __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
                                             const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [nstage][CAPX] or nullptr */, const int nstage = 0,
                                             const Pro pro = Pro())
 {
     const int t = threadIdx.x;
+    const bool d2 = !LEAN && (a.dim > 1), aux = !LEAN && (a.auxdst != nullptr);
     const long long b0 = (long long)bidx * EB;
     // run-state words and this lane's terms are fetched together (one memory round trip, not two)
     const int s_dead = st->dead, s_do = st->do_resample, call = st->cur_call, dbg = st->debug_stop;
@@ -1988,8 +1992,8 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         for (int k = 0; k < EL; k++) {
             const long long j = b0 + ebase + 64 * k;
             if (j < a.nw) {
-                if (a.xdst) { xs0[k] = a.xsrc[j]; if (a.dim > 1) xs1[k] = a.xsrc[a.xstride + j]; }
-                if (a.auxdst) axs[k] = a.auxsrc[j];
+                if (a.xdst) { xs0[k] = a.xsrc[j]; if (d2) xs1[k] = a.xsrc[a.xstride + j]; }
+                if (aux) axs[k] = a.auxsrc[j];
             }
         }
     }
@@ -2083,10 +2087,10 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         // particles going straight to HBM that address traffic, not the bytes, bounded this stage.  Plain case
         // (scalar state, nothing else to carry): scatter into LDS, then store the block's output range coalesced.
         // (the second state component and the auxiliary log-weights are staged the same way when the launch provides room)
-        const int need = (a.dim > 1 ? 2 : 1) + (a.auxdst ? 1 : 0);
-        const bool stage = (lx != nullptr) && a.xdst && !anc && need <= nstage && (Te - Tb) <= CAPX;
-        double* lx1 = lx + CAPX;                                   // second state component
-        double* lxa = lx + (a.dim > 1 ? 2 : 1) * CAPX;             // auxiliary log-weights
+        const int need = (d2 ? 2 : 1) + (aux ? 1 : 0);
+        const bool stage = (lx != nullptr) && a.xdst && !anc && need <= nstage && (Te - Tb) <= CAP;
+        double* lx1 = lx + CAP;                                    // second state component
+        double* lxa = lx + (d2 ? 2 : 1) * CAP;                     // auxiliary log-weights
         int Tp[EL], Ts[EL];                                        // all the counts first: one LDS round trip, not EL
 #pragma unroll
         for (int k = 0; k < EL; k++) { const int e = ebase + 64 * k; Ts[k] = Tl[e]; Tp[k] = (e == 0) ? Tb : Tl[e - 1]; }
@@ -2101,8 +2105,8 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
                 for (int k = 0; k < EL; k++) {
                     if (j < Ts[k]) {
                         lx[Tp[k] + j] = xs0[k];
-                        if (a.dim > 1) lx1[Tp[k] + j] = xs1[k];
-                        if (a.auxdst) lxa[Tp[k] + j] = axs[k];
+                        if (d2) lx1[Tp[k] + j] = xs1[k];
+                        if (aux) lxa[Tp[k] + j] = axs[k];
                     }
                 }
             }
@@ -2114,9 +2118,9 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
                     if (anc) anc[i] = (int)(src + 1);                    // 1-based (src/resampling.cpp:36,62)
                     if (a.xdst) {
                         a.xdst[i] = xs0[k];
-                        if (a.dim > 1) a.xdst[a.xstride + i] = xs1[k];
+                        if (d2) a.xdst[a.xstride + i] = xs1[k];
                     }
-                    if (a.auxdst) a.auxdst[i] = axs[k];
+                    if (aux) a.auxdst[i] = axs[k];
                 }
             }
         }
@@ -2127,7 +2131,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
             BSSM_STAMP(st, dbg, 3, 10, stamper);
             if (stage) {
                 // all the LDS reads first, then the stores (a read-store pair per trip waited ~450 cycles a trip)
-                constexpr int R = CAPX / NT;
+                constexpr int R = CAP / NT;
                 double xv[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; xv[r] = (i < Te) ? lx[i - Tb] : 0.0; }
@@ -2137,7 +2141,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
                     // the next observation's transition + weight on the staged particles, a PAIR of outputs per lane (the
                     // generator gives two normals per block, keyed by the pair's index -- exactly k_step's arithmetic);
                     // a pair cut by the range's ends is finished by the neighbouring workgroup
-                    constexpr int R2 = (CAPX / 2 + 1 + NT - 1) / NT;
+                    constexpr int R2 = (CAP / 2 + 1 + NT - 1) / NT;
                     const int q0 = Tb >> 1;
 #pragma unroll
                     for (int r = 0; r < R2; r++) {
@@ -2160,12 +2164,12 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
                         }
                     }
                 }
-                if (a.dim > 1) for (int i = Tb + t; i < Te; i += NT) { const double x1 = lx1[i - Tb]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
-                if (a.auxdst) for (int i = Tb + t; i < Te; i += NT) a.auxdst[i] = lxa[i - Tb];
+                if (d2) for (int i = Tb + t; i < Te; i += NT) { const double x1 = lx1[i - Tb]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
+                if (aux) for (int i = Tb + t; i < Te; i += NT) a.auxdst[i] = lxa[i - Tb];
             } else {
                 for (int i = Tb + t; i < Te; i += NT) {
                     acc0 += a.xdst[i] * invN;
-                    if (a.dim > 1) acc1 += a.xdst[a.xstride + i] * invN;
+                    if (d2) acc1 += a.xdst[a.xstride + i] * invN;
                 }
                 if constexpr (STEP) step_in_place = true;
             }
@@ -2199,8 +2203,8 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
     BSSM_STAMP(st, dbg, 3, 5, stamper);
     if (a.se_part) {
         acc0 = block_sum(acc0, sm.sh4);
-        if (a.dim > 1) acc1 = block_sum(acc1, sm.sh4);
-        if (t == 0) { a.se_part[(long long)bidx * a.dim] = acc0; if (a.dim > 1) a.se_part[(long long)bidx * a.dim + 1] = acc1; }
+        if (d2) acc1 = block_sum(acc1, sm.sh4);
+        if (t == 0) { a.se_part[(long long)bidx * a.dim] = acc0; if (d2) a.se_part[(long long)bidx * a.dim + 1] = acc1; }
     }
     BSSM_STAMP(st, dbg, 3, 6, stamper);
 }
@@ -2209,10 +2213,13 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
 // prev_brec != nullptr: every workgroup resolves the MODE_P pass for itself (its own exact incoming state) instead of a
 // k_resolve<P> launch in between.
 // STEP: the next observation's transition_fn + weight_fn run on the resampled particles before they leave the workgroup.
-template <int KIND, bool INRES = false, bool STEP = false>
+constexpr int CAP_LEAN = 2304;   // 18 KiB of staging: with the 22.3 KiB of static LDS four workgroups fit a CU
+template <int KIND, bool INRES = false, bool STEP = false, bool LEAN = false>
 __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st, const BlockRec* __restrict__ prev_brec,
                                               const SideList* __restrict__ prev_side, int boff, int nblk_g)
 {
+    static_assert(!LEAN || (!INRES && !STEP), "the lean variant is the plain expansion");
+    constexpr int CAP = LEAN ? CAP_LEAN : CAPX;
     const int bidx = (int)blockIdx.x + boff, nblk = nblk_g ? nblk_g : (int)gridDim.x;
     __shared__ SegSmem sm;
     __shared__ uint64_t tin[NT];
@@ -2222,10 +2229,10 @@ __global__ __launch_bounds__(NT) void k_apply(ApplyArgs a, DevState* st, const B
     if constexpr (INRES) {
         InResolve<MODE_P> pro; pro.sm = &sm; pro.rs = reinterpret_cast<ResolveSmem*>(lx); pro.brec = prev_brec; pro.side = prev_side;
         pro.B = nblk; pro.upto = bidx; pro.w = a.w; pro.nw = a.nw; pro.total = b2d(st->total_bits); pro.st = st; pro.stats = (bidx == nblk - 1);
-        apply_block<KIND, false, InResolve<MODE_P>, STEP>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage, pro);
+        apply_block<KIND, false, InResolve<MODE_P>, STEP, CAP, LEAN>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage, pro);
     } else {
         (void)prev_brec; (void)prev_side;
-        apply_block<KIND, false, NoResolve, STEP>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage);
+        apply_block<KIND, false, NoResolve, STEP, CAP, LEAN>(sm, tin, Tl, Tbegin, bidx, nblk, a, st, a.nstage ? lx : nullptr, a.nstage);
     }
 }
 

@@ -43,6 +43,8 @@ KERNEL_BYTES = {
     "k_local<P>": 8.0,                          # read w
     "k_apply<systematic>": 24.0,                # read w, read x'[a], write x
     "k_apply<stratified>": 24.0,
+    "k_apply<systematic,lean>": 24.0,
+    "k_apply<stratified,lean>": 24.0,
     "k_apply<systematic>(+resolve<P>)": 24.0,   # the same; every workgroup also reads the block records of the pass before it
     "k_apply<stratified>(+resolve<P>)": 24.0,
     "k_local<P>(+resolve<W>)": 8.0,
