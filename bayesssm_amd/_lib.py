@@ -159,7 +159,7 @@ class Context:
     def synchronize(self):
         check(load().bssm_ctx_synchronize(self._h))
 
-    OPTIONS = {"record_window": 1, "batch_literal_max": 2, "stage_expansion": 3, "inkernel_resolve": 4, "debug_stop": 5, "fuse_step": 6, "renormalize": 7}
+    OPTIONS = {"record_window": 1, "batch_literal_max": 2, "stage_expansion": 3, "inkernel_resolve": 4, "debug_stop": 5, "fuse_step": 6, "renormalize": 7, "recompute_lw": 8}
 
     def set_option(self, name, value):
         """per-context test aid / A/B switch (include/bayesssm_amd.h BSSM_OPT_*)"""

@@ -56,6 +56,7 @@ struct bssm_ctx {
     int opt_inkernel_resolve = 1;  // grids of <= 2 NT blocks: resolve inside the consuming kernels instead of k_resolve launches
     int opt_renormalize = 1;       // filters: 1 = the resampler divides the normalised weights by their exact sum again (src/resampling.cpp:24,51),
                                    // 0 = that division (by 1 +- a few 1e-14) is folded away: one exact pass instead of two
+    int opt_recompute_lw = 1;      // bootstrap filters on the Gaussian-observation models: log-weights re-evaluated in k_weights instead of stored by k_step
     int opt_fuse_step = 0;         // SISR bootstrap filters: the next observation's transition + weight inside the expansion kernel
                                    // (off: measured slower -- 7 generator pairs per lane at 2 waves per SIMD cost the expansion kernel 7.7 us,
                                    //  the k_step launch they replace costs 11.2 us but the per-block partials still need a 5.4 us launch)
@@ -210,6 +211,7 @@ extern "C" int bssm_ctx_set_option(bssm_ctx* c, int option, int value)
         case BSSM_OPT_INKERNEL_RESOLVE: c->opt_inkernel_resolve = value; break;
         case BSSM_OPT_DEBUG_STOP: c->opt_debug_stop = value; break;
         case BSSM_OPT_FUSE_STEP: c->opt_fuse_step = value; break;
+        case BSSM_OPT_RECOMPUTE_LW: c->opt_recompute_lw = value ? 1 : 0; break;
         case BSSM_OPT_RENORMALIZE: c->opt_renormalize = value ? 1 : 0; break;
         default: ARGFAIL("bssm_ctx_set_option: unknown option");
     }
@@ -287,6 +289,7 @@ static PhiloxKey make_key(unsigned long long seed, unsigned long long stream)
 struct ResampleLaunch {
     // filter path: weights are produced from log-weights inside the first scan kernel
     const double* d_lw = nullptr; int plan = PLAN_RESAMPLE_ONLY; int check_degenerate = 0;
+    const double* xw = nullptr; double yw = 0, syw = 1, lsyw = 0;      // log-weights not stored: dnorm(yw, xw[j], syw) re-evaluated by the normalising kernel
     int obs_i = 0; int resample_algorithm = 1; double threshold = 0; double* d_ess = nullptr; double* d_llh = nullptr; int* d_resampled = nullptr;
     const double* d_w; long long nw; int n; int kind;
     const double* d_u; long long u_stride; PhiloxKey key;
@@ -304,7 +307,7 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
     const size_t shm = (size_t)B * sizeof(BlockRec);
     const int boff = c->sh_boff, G = c->sh_nloc ? c->sh_nloc : B;        // launch grid: all blocks, or this rank's (sharded)
     const int Bg = c->sh_nloc ? B : 0;                                   // global block count handed to the kernels when sharded
-    FromLw f; f.lw = r.d_lw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
+    FromLw f; f.lw = r.d_lw; f.xw = r.xw; f.yw = r.yw; f.syw = r.syw; f.lsyw = r.lsyw; f.w_out = const_cast<double*>(r.d_w); f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
     f.lead = boff; f.pub = c->sh_nloc ? boff + G / 2 : B / 2;
     const bool fold = r.d_lw && !c->opt_renormalize && !c->sh_nloc && r.kind != BSSM_MULTINOMIAL_R;
     f.fold = fold ? 1 : 0;
@@ -544,10 +547,11 @@ extern "C" int bssm_pf_noise_shape(int algorithm, int T, const int* obs_times, i
 
 template <int MODEL>
 static void launch_step(bssm_ctx* c, bool trans, int weight, bool subaux, double* x, long long N, int B,
-                        const ModelPar& par, double y, const NoiseSrc& ns)
+                        const ModelPar& par, double y, const NoiseSrc& ns, bool store_lw = true)
 {
     if (c->sh_nloc) B = c->sh_nloc;                  // sharded: this rank's blocks only (k_step adds the block offset)
-#define STEP_ARGS x, x, c->lw, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff
+    double* lw_out = store_lw ? c->lw : nullptr;     // nullptr: the normalising kernel re-evaluates the log-weights (FromLw::xw)
+#define STEP_ARGS x, x, lw_out, c->auxg, N, par, y, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff
     if (trans && weight == 1 && !subaux) LAUNCH(c, "k_step<trans+weight>", (k_step<MODEL, true, 1, false>), B, NTS, 0, STEP_ARGS);
     else if (trans && weight == 1 && subaux) LAUNCH(c, "k_step<trans+weight-aux>", (k_step<MODEL, true, 1, true>), B, NTS, 0, STEP_ARGS);
     else if (trans && weight == 0) LAUNCH(c, "k_step<trans>", (k_step<MODEL, true, 0, false>), B, NTS, 0, STEP_ARGS);
@@ -570,10 +574,10 @@ static void launch_step_sir(bssm_ctx* c, bool trans, int weight, bool subaux, do
 }
 
 static void launch_step_model(bssm_ctx* c, int model, bool trans, int weight, bool subaux, double* x, long long N, int B,
-                              const ModelPar& par, double y, const NoiseSrc& ns)
+                              const ModelPar& par, double y, const NoiseSrc& ns, bool store_lw = true)
 {
-    if (model == BSSM_MODEL_LG) launch_step<0>(c, trans, weight, subaux, x, N, B, par, y, ns);
-    else if (model == BSSM_MODEL_AR1SIN) launch_step<1>(c, trans, weight, subaux, x, N, B, par, y, ns);
+    if (model == BSSM_MODEL_LG) launch_step<0>(c, trans, weight, subaux, x, N, B, par, y, ns, store_lw);
+    else if (model == BSSM_MODEL_AR1SIN) launch_step<1>(c, trans, weight, subaux, x, N, B, par, y, ns, store_lw);
     else launch_step_sir(c, trans, weight, subaux, x, N, B, par, y, ns);
 }
 
@@ -679,6 +683,9 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     }
     int ktrans = 0, prev_t = 0;
     bool stepped_ahead = false;
+    // bootstrap / resample-move filter on the Gaussian-observation models: k_step does not store the log-weights, k_weights
+    // re-evaluates dnorm(y, x) on the particles (8 MB less written per observation at N = 2^20, the same 8 MB read)
+    const bool relw = c->opt_recompute_lw && !apf && !sir && !c->opt_fuse_step;
     for (int i = 1; i <= T; i++) {                                                        // :123
         const int ot = cfg->obs_times ? cfg->obs_times[i - 1] : i;
         const int gap = ot - prev_t;                                                      // :124
@@ -699,7 +706,7 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         } else for (int step = 1; step <= gap; step++) {
             const bool fuse_w = (!apf && step == gap);
             if (fuse_w) next_gmax();
-            launch_step_model(c, cfg->model, true, fuse_w ? 1 : 0, false, X0, N, B, par, yi, noise(ktrans));
+            launch_step_model(c, cfg->model, true, fuse_w ? 1 : 0, false, X0, N, B, par, yi, noise(ktrans), !relw);
             ktrans++;
         }
         // can the NEXT observation's transition + weight ride along with this observation's expansion?  (bootstrap filter
@@ -725,13 +732,15 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
             // obs_times repeats a time: no transition, weights on the current particles
             NoiseSrc ns = noise(0);
             next_gmax();
-            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff);
-            else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, c->lw, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff);
+            double* lwo = relw ? nullptr : c->lw;
+            if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_step<weight>", (k_step<0, false, 1, false>), B, NTS, 0, X0, X0, lwo, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff);
+            else if (cfg->model == BSSM_MODEL_AR1SIN) LAUNCH(c, "k_step<weight>", (k_step<1, false, 1, false>), B, NTS, 0, X0, X0, lwo, c->auxg, N, par, yi, ns, c->pm, c->ps, c->pq, c->st, c->gmax_cur, c->sh_boff);
             else launch_step_sir(c, false, 1, false, X0, N, B, par, yi, ns);
         }
         double* se_row = separt + (size_t)i * B * dim;
         // normalise (:204-207) + loglik/ESS/decision (:208-218) + resample (:220-224), fused into the scan kernels
         r.d_lw = c->lw; r.plan = PLAN_PF; r.check_degenerate = 1; r.obs_i = i; r.resample_algorithm = resample_algorithm;
+        if (relw) { r.xw = X0; r.yw = yi; r.syw = par.sy; r.lsyw = par.log_sy; }
         r.threshold = threshold; r.d_ess = (double*)d_ess; r.d_llh = (double*)d_llh; r.d_resampled = (int*)d_resampled;
         r.xsrc = X0; r.xdst = X1; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = se_row;
         if (stepped_ahead) { r.step_model = cfg->model; r.step_par = par; r.step_y = cfg->y[i]; r.step_ns = noise(ktrans); }
@@ -940,7 +949,7 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
         // (1) the log-sum-exp partials of every block
         if ((rc = gather_blocks(c->pm, 8)) || (rc = gather_blocks(c->ps, 8)) || (rc = gather_blocks(c->pq, 8))) return rc;
         double* se_row = separt + (size_t)i * B;
-        FromLw f; f.lw = c->lw; f.w_out = c->w; f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B; f.gmax = nullptr; f.fold = 0;
+        FromLw f; f.lw = c->lw; f.xw = nullptr; f.w_out = c->w; f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B; f.gmax = nullptr; f.fold = 0;
         f.lead = boff; f.pub = boff + nloc / 2; f.ain_out = c->ain_w; f.plan = PLAN_PF; f.N = N; f.obs_i = i;
         f.resample_algorithm = resample_algorithm; f.threshold = threshold;
         f.ess_out = (double*)d_ess; f.llh_out = (double*)d_llh; f.resampled_out = (int*)d_resampled;

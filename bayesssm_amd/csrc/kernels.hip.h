@@ -436,8 +436,9 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
                 l1 = r_dnorm_log(y, x1, par.sy, par.log_sy);
             }
             if (SUBAUX) { l0 = l0 - auxg[j]; if (two) l1 = l1 - auxg[j + 1]; }
-            if (two) { double2 q; q.x = l0; q.y = l1; *reinterpret_cast<double2*>(lw + j) = q; }
-            else { lw[j] = l0; l1 = -INFINITY; }
+            // (lw == nullptr: the normalising kernel recomputes the log-weights from the particles it reads anyway -- FromLw::xw)
+            if (!two) l1 = -INFINITY;
+            if (lw) { if (two) { double2 q; q.x = l0; q.y = l1; *reinterpret_cast<double2*>(lw + j) = q; } else lw[j] = l0; }
         }
     }
     if (WEIGHT) {
@@ -1072,6 +1073,7 @@ struct NoResolve { static constexpr bool active = false; __device__ __forceinlin
 
 struct FromLw {
     const double* lw; double* w_out; const double* pm; const double* ps; const double* pq; int nb;
+    const double* xw; double yw, syw, lsyw;   // xw != nullptr: log-weights = dnorm(yw, xw[j], syw, log = TRUE), evaluated here exactly as k_step evaluated them (it did not store them)
     const unsigned long long* gmax;      // key of max(pm[0..nb)) left by the step kernel's atomics, or nullptr (then reduced here)
     int fold;                            // 1: the resampler's own normalisation (prob = w / sum(w), src/resampling.cpp:24,51) is folded into
                                          // this kernel's  w = exp(lw - max) / sum: total is taken as 1 and this pass's records ARE the
@@ -1131,13 +1133,14 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         // issue this thread's log-weight loads first: their latency hides under the reductions below
         const long long j0 = b0 + (long long)t * EL;
         double l8[EL];
+        const double* lsrc = f.xw ? f.xw : f.lw;
         if (j0 + EL <= nw) {
-            const double2* p2 = reinterpret_cast<const double2*>(f.lw + j0);
+            const double2* p2 = reinterpret_cast<const double2*>(lsrc + j0);
 #pragma unroll
             for (int k = 0; k < EL / 2; k++) { const double2 q2 = p2[k]; l8[2 * k] = q2.x; l8[2 * k + 1] = q2.y; }
         } else {
 #pragma unroll
-            for (int k = 0; k < EL; k++) l8[k] = (j0 + k < nw) ? f.lw[j0 + k] : -INFINITY;
+            for (int k = 0; k < EL; k++) l8[k] = (j0 + k < nw) ? lsrc[j0 + k] : (f.xw ? 0.0 : -INFINITY);
         }
         // Thread t holds the partials of the L consecutive blocks t L .. t L + L - 1 (L = nb / NT rounded up): all three
         // arrays and the grid maximum are fetched up front (one memory round trip).
@@ -1226,6 +1229,10 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         __syncthreads();
         a_in = sm.bcast;
         BSSM_STAMP(st, dbg, 2, 8, stamper);
+        if (f.xw) {
+#pragma unroll
+            for (int k = 0; k < EL; k++) l8[k] = r_dnorm_log(f.yw, l8[k], f.syw, f.lsyw);
+        }
 #pragma unroll
         for (int k = 0; k < EL; k++) v[k] = (j0 + k < nw) ? exp(l8[k] - M) / S : 0.0;        // :205-207
         if (j0 + EL <= nw || (LIT && j0 < nw)) {             // (LIT: the partly filled lane stores its zero padding too -- the in-order pass reads whole lanes)
@@ -2734,7 +2741,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
             step_emul<MODEL, false, 2>(sh16, xa, AUXLW, nullptr, N, par, yi, ns, &pm1, &ps1, &pq1);
             __syncthreads();
             FromLw fa;
-            fa.lw = AUXLW; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.gmax = nullptr; fa.fold = g.fold; fa.lead = 0; fa.pub = 0; fa.ain_out = &ainw1;
+            fa.lw = AUXLW; fa.xw = nullptr; fa.w_out = LW; fa.pm = &pm1; fa.ps = &ps1; fa.pq = &pq1; fa.nb = 1; fa.gmax = nullptr; fa.fold = g.fold; fa.lead = 0; fa.pub = 0; fa.ain_out = &ainw1;
             fa.plan = PLAN_AUX; fa.N = N; fa.obs_i = i; fa.resample_algorithm = g.resample_algorithm; fa.threshold = g.threshold;
             fa.ess_out = nullptr; fa.llh_out = nullptr; fa.resampled_out = nullptr;
             if (lit) local_block<MODE_W, true, NT, true>(sm, tin, es, 0, 1, LW, N, nullptr, g.lim, &br, nullptr, &st, fa, NoResolve(), nullptr, 1);
@@ -2777,7 +2784,7 @@ __global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_bat
         }
         if (t == 0) { sep[0] = 0.0; sep[1] = 0.0; }
         FromLw fl;
-        fl.lw = LW; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.gmax = nullptr; fl.fold = g.fold; fl.lead = 0; fl.pub = 0; fl.ain_out = &ainw1;
+        fl.lw = LW; fl.xw = nullptr; fl.w_out = LW; fl.pm = &pm1; fl.ps = &ps1; fl.pq = &pq1; fl.nb = 1; fl.gmax = nullptr; fl.fold = g.fold; fl.lead = 0; fl.pub = 0; fl.ain_out = &ainw1;
         fl.plan = PLAN_PF; fl.N = N; fl.obs_i = i; fl.resample_algorithm = g.resample_algorithm; fl.threshold = g.threshold;
         fl.ess_out = g.ess + (long long)fi * (T + 1); fl.llh_out = g.llh + (long long)fi * T; fl.resampled_out = nullptr;
         // normalise + loglik/ESS/decision + the exact sum(weights) of the block (:204-218, src/resampling.cpp:20-24)

@@ -37,8 +37,8 @@ SWEEP_BYTES = 68.0
 SWEEP_READ_BYTES = 40.0
 # per-kernel algorithmic bytes per particle (this implementation's kernel split, d = 1)
 KERNEL_BYTES = {
-    "k_step<trans+weight>": 24.0,               # read x, write x', write lw
-    "k_weights(normalize+local<W>)": 16.0,      # read lw, write w
+    "k_step<trans+weight>": 16.0,               # read x, write x'  (the log-weights are not stored: k_weights re-evaluates them)
+    "k_weights(normalize+local<W>)": 16.0,      # read x' (-> log-weights), write w
     "k_local<W>": 8.0,                          # read w
     "k_local<P>": 8.0,                          # read w
     "k_apply<systematic>": 24.0,                # read w, read x'[a], write x

@@ -102,6 +102,7 @@ void* bssm_ctx_stream(bssm_ctx* ctx);
 #define BSSM_OPT_INKERNEL_RESOLVE 4    /* [1] grids of <= 512 blocks: the consuming kernels resolve the pass before them; 0 = k_resolve launches */
 #define BSSM_OPT_DEBUG_STOP 5          /* [0] DEV builds (make DEV=1): stage stamps */
 #define BSSM_OPT_RENORMALIZE 7         /* [1] filters: the resampler's prob = weights / sum(weights) on the already normalised weights (src/resampling.cpp:24,51); 0 folds it away */
+#define BSSM_OPT_RECOMPUTE_LW 8        /* [1] bootstrap filters, Gaussian-observation models: k_step does not store the log-weights, k_weights re-evaluates them */
 #define BSSM_OPT_FUSE_STEP 6           /* [0] SISR bootstrap filters: the next observation's transition + weight inside the expansion kernel */
 int bssm_ctx_set_option(bssm_ctx* ctx, int option, int value);
 int bssm_ctx_get_stamps(bssm_ctx* ctx, long long* out /* [4][16] */);
