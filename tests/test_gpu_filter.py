@@ -476,3 +476,35 @@ def test_fused_step_equals_separate_launch(B, oracle, model, rf):
                 assert (outs[0][k][key] == outs[1][k][key]).all(), (N, key)
     cx.set_option("fuse_step", 0)
     cx.close()
+
+
+@pytest.mark.parametrize("alg", ["BPF", "RMPF"])
+def test_recomputed_log_weights_equal_stored_ones(B, alg):
+    """Option recompute_lw (default 1): k_step keeps the log-weights in registers and k_weights re-evaluates dnorm(y, x) on the
+    particles instead of reading stored values -- same function on the same inputs, so every output is bit-identical with the
+    option off (both models, SISR / SISAR / SIS, gaps and repeated observation times, ragged N, a degenerate observation)."""
+    cx = B.Context(0, 1 << 17, 1)
+    rng = np.random.default_rng(11)
+    for model in ("lg", "ar1sin"):
+        m = B.models.linear_gaussian() if model == "lg" else B.models.ar1_sin()
+        for N, T, ot, ra in ((50001, 10, None, "SISR"), (4097, 8, [1, 2, 2, 5, 6, 6, 9, 10], "SISAR"), (1 << 17, 4, None, "SIS"), (300, 6, None, "SISR")):
+            ys = _simulate(rng, T, sin=(model == "ar1sin"))
+            if N == 300:
+                ys[3] = 1e6               # all(log_weights < -1e8): the early return
+            outs = []
+            for on in (1, 0):
+                cx.set_option("recompute_lw", on)
+                kw = dict(resample_algorithm=ra, resample_fn="stratified", return_particles=(N == 4097), obs_times=ot, seed=3, stream=N,
+                          ctx=cx, phi=0.8, sigma_x=1.0, sigma_y=0.7)
+                if alg == "BPF":
+                    outs.append(B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, **kw))
+                else:
+                    outs.append(B.resample_move_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, m.rw_move_fn(0.3), **kw))
+            a, b2 = outs
+            assert (a["loglike"] == b2["loglike"]) or (np.isinf(a["loglike"]) and np.isinf(b2["loglike"]))
+            for key in ("loglike_history", "ess", "state_est"):
+                np.testing.assert_array_equal(a[key], b2[key], err_msg="%s %s N=%d" % (model, key, N))
+            if N == 4097:
+                np.testing.assert_array_equal(a["weights_history"], b2["weights_history"])
+    cx.set_option("recompute_lw", 1)
+    cx.close()
