@@ -43,6 +43,9 @@ static_assert(NT * EL == 2048 && (NT == 256 || NT == 512) , "a scan workgroup co
 constexpr int EB = NT * EL;      // 2048 terms per workgroup
 constexpr int MAXB = 2048;       // max scan workgroups  => N <= 2^22 per filter
 
+// The bulk stores of a kernel (resampled particles, normalised weights) are streaming stores: the data is next read by another
+// kernel, from other XCDs, and a kernel ends when its stores have drained -- non-temporal ones drain ~0.5 us sooner per kernel.
+typedef double v2d_nt __attribute__((ext_vector_type(2)));
 constexpr int MODE_W = 0;        // terms are the weights themselves        (total = sum(w))
 constexpr int MODE_P = 1;        // terms are prob = w / total              (cum = cumsum(prob))
 
@@ -1238,7 +1241,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         if (j0 + EL <= nw || (LIT && j0 < nw)) {             // (LIT: the partly filled lane stores its zero padding too -- the in-order pass reads whole lanes)
             double2* p2 = reinterpret_cast<double2*>(f.w_out + j0);
 #pragma unroll
-            for (int k = 0; k < EL / 2; k++) { double2 q2; q2.x = v[2 * k]; q2.y = v[2 * k + 1]; p2[k] = q2; }
+            for (int k = 0; k < EL / 2; k++) { v2d_nt q2; q2.x = v[2 * k]; q2.y = v[2 * k + 1]; __builtin_nontemporal_store(q2, reinterpret_cast<v2d_nt*>(p2 + k)); }
         } else {
 #pragma unroll
             for (int k = 0; k < EL; k++) if (j0 + k < nw) f.w_out[j0 + k] = v[k];
@@ -2143,7 +2146,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
 #pragma unroll
                 for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; xv[r] = (i < Te) ? lx[i - Tb] : 0.0; }
 #pragma unroll
-                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; if (i < Te) { if (!STEP) a.xdst[i] = xv[r]; acc0 += xv[r] * invN; } }
+                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; if (i < Te) { if (!STEP) __builtin_nontemporal_store(xv[r], a.xdst + i); acc0 += xv[r] * invN; } }
                 if constexpr (STEP) {
                     // the next observation's transition + weight on the staged particles, a PAIR of outputs per lane (the
                     // generator gives two normals per block, keyed by the pair's index -- exactly k_step's arithmetic);
