@@ -777,8 +777,10 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     if (res->early_return_step) *res->early_return_step = h.dead;
     if (res->n_res_calls) *res->n_res_calls = h.res_calls;
     if (res->scan_stats) { res->scan_stats[0] = h.stat_hard_blocks; res->scan_stats[1] = h.stat_serial_walks; res->scan_stats[2] = h.stat_literal_terms; }
-    if (h.dead) {   // the reference returns at once: later rows keep their initial values (:90-97)
-        for (int i = h.dead; i <= T; i++) { res->ess[i] = 0.0; for (int d = 0; d < dim; d++) res->state_est[(size_t)i * dim + d] = 0.0; }
+    if (h.dead) {   // the reference returns at once: later rows keep their initial values -- numeric(out_steps) = 0 for a scalar
+                    // state, matrix(NA, out_steps, d) for d > 1 (:90-97); NaN stands for NA_real_ at the C ABI
+        const double se_init = (dim > 1) ? (double)NAN : 0.0;
+        for (int i = h.dead; i <= T; i++) { res->ess[i] = 0.0; for (int d = 0; d < dim; d++) res->state_est[(size_t)i * dim + d] = se_init; }
         for (int i = h.dead; i < T; i++) res->loglike_history[i] = 0.0;
     }
     if (h.flags) {
@@ -1148,7 +1150,7 @@ extern "C" int bssm_pf_run_batch(bssm_ctx* c, const bssm_pf_config* cfg, int n_f
         if (dead[f]) {                                // the reference returns at once: later rows keep their initial values (:90-97)
             for (int i = dead[f]; i <= T; i++) {
                 if (res->ess) res->ess[(size_t)f * (T + 1) + i] = 0.0;
-                if (res->state_est) for (int d = 0; d < dim; d++) res->state_est[((size_t)f * (T + 1) + i) * dim + d] = 0.0;
+                if (res->state_est) for (int d = 0; d < dim; d++) res->state_est[((size_t)f * (T + 1) + i) * dim + d] = (dim > 1) ? (double)NAN : 0.0;   // matrix(NA) for d > 1 (:90-95)
             }
             if (res->loglike_history) for (int i = dead[f]; i < T; i++) res->loglike_history[(size_t)f * T + i] = 0.0;
         }

@@ -961,7 +961,9 @@ __device__ __forceinline__ bool block_resolve(SegSmem& sm, const BlockScan& bs, 
         if (lane < nb) { sm.bnd_ent[lane] = my_ent; sm.seg_start[lane + 1] = my_out; }
     }
     __syncthreads();
-    if (sm.fail) return false;
+    // (not a re-read of sm.fail: a wave that is late here could see the flag another wave sets below for a window miss, leave
+    //  early and miss the barrier behind the checks.  The only setter in front of this point is the block-uniform test.)
+    if (bs.nb > MAXBND) return false;
     bool ok = true;
     if (bs.isb) ent = sm.bnd_ent[bs.seg];
     else {

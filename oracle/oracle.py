@@ -152,7 +152,9 @@ def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
         assert z_trans.size >= max_trans * N, (z_trans.size, max_trans, N)
     need_u = max_res * (1 if resample_fn == "systematic" else N)
     assert u_res.size >= need_u, (u_res.size, need_u)
-    state_est = np.zeros((T + 1, D)) if D > 1 else np.zeros(T + 1)
+    # numeric(out_steps) for a scalar state, matrix(NA, out_steps, d) otherwise (R/particle_filter_core.R:90-95):
+    # rows the filter never reaches (degenerate early return, :189-202) keep these initial values
+    state_est = np.full((T + 1, D), np.nan) if D > 1 else np.zeros(T + 1)
     ess = np.zeros(T + 1)
     llh = np.zeros(T)
     ll = np.zeros(1)

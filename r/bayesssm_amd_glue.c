@@ -5,8 +5,11 @@
  * R side R/RcppExports.R:4-14, callers R/resampling.R:19,26,39,46,59,66), and the fused filter / PMMH chain get `.Call`s
  * of their own.  Everything below the glue is the plain C ABI of include/bayesssm_amd.h.
  *
- * NOT compiled in this repository's image: there is no R toolchain here (no R.h / Rinternals.h).  The C ABI it calls is
- * exercised through ctypes (bayesssm_amd/_lib.py, tests/) and from plain C (tests/harness/abi_smoke.c).
+ * NOT built into a loadable object in this repository's image: there is no R toolchain here (no R.h / Rinternals.h).  It
+ * is syntax- and type-checked by `gcc -fsyntax-only` against a declarations-only stub of the R API
+ * (tests/harness/r_api_stub/, tests/test_abi_and_host.py::test_r_glue_compiles_against_api_stub) -- compile hygiene, not
+ * parity evidence.  The C ABI it calls is exercised through ctypes (bayesssm_amd/_lib.py, tests/) and from plain C
+ * (tests/harness/abi_smoke.c).
  *
  * Random draws: the reference draws inside its C++ under Rcpp::RNGScope (src/RcppExports.cpp:18,30,42).  Here the glue
  * draws the same variates in the same order from R's generator (unif_rand() between GetRNGstate/PutRNGstate) and passes
@@ -57,13 +60,27 @@ static double *draw_uniforms(int n)
     return U;
 }
 
+/* The reference validates BEFORE it draws (src/resampling.cpp:6-8, :17-23, :44-50 come before :11, :28, :55), so a call that
+ * stops with an error leaves R's generator where it was.  Same order here: any(weights < 0) first, then the in-order
+ * sum (Rcpp sugar sum: plain double adds) against 0 -- no draw has been made when either one stops. */
+static void validate_weights(SEXP w)
+{
+    const double *wp = REAL(w);
+    const R_xlen_t m = XLENGTH(w);
+    double total = 0.0;
+    for (R_xlen_t i = 0; i < m; i++) if (wp[i] < 0) Rf_error("Weights must be non-negative");
+    for (R_xlen_t i = 0; i < m; i++) total += wp[i];
+    if (total == 0) Rf_error("Sum of weights must be greater than 0");
+}
+
 /* resample_systematic_cpp(n, weights): src/resampling.cpp:43-66 */
 SEXP _bayesSSM_resample_systematic_cpp(SEXP nSEXP, SEXP weightsSEXP)
 {
     const int n = Rf_asInteger(nSEXP);
     SEXP w = PROTECT(Rf_coerceVector(weightsSEXP, REALSXP));
     SEXP out = PROTECT(Rf_allocVector(INTSXP, n));
-    const double U = draw_uniforms(1)[0];
+    validate_weights(w);                           /* (Rf_error unwinds the protect stack itself) */
+    const double U = draw_uniforms(1)[0];          /* R::runif(0, 1), :55 */
     const int st = bssm_resample_systematic(get_ctx(n > LENGTH(w) ? n : LENGTH(w), 1), n, REAL(w), LENGTH(w), U, INTEGER(out));
     UNPROTECT(2);
     check(st);
@@ -76,7 +93,8 @@ SEXP _bayesSSM_resample_stratified_cpp(SEXP nSEXP, SEXP weightsSEXP)
     const int n = Rf_asInteger(nSEXP);
     SEXP w = PROTECT(Rf_coerceVector(weightsSEXP, REALSXP));
     SEXP out = PROTECT(Rf_allocVector(INTSXP, n));
-    const double *U = draw_uniforms(n);
+    validate_weights(w);
+    const double *U = draw_uniforms(n);            /* Rcpp::runif(n), :28 */
     const int st = bssm_resample_stratified(get_ctx(n > LENGTH(w) ? n : LENGTH(w), 1), n, REAL(w), LENGTH(w), U, INTEGER(out));
     UNPROTECT(2);
     check(st);
@@ -89,13 +107,9 @@ SEXP _bayesSSM_resample_multinomial_cpp(SEXP nSEXP, SEXP weightsSEXP)
     const int n = Rf_asInteger(nSEXP);
     SEXP w = PROTECT(Rf_coerceVector(weightsSEXP, REALSXP));
     SEXP out = PROTECT(Rf_allocVector(INTSXP, n));
-    /* validation comes first in the reference (:6-8) and consumes no draws: a failing call must leave the stream untouched */
-    const double *wp = REAL(w);
-    double total = 0.0;
-    for (int i = 0; i < LENGTH(w); i++) { if (wp[i] < 0) { UNPROTECT(2); Rf_error("Weights must be non-negative"); } total += wp[i]; }
-    if (total == 0) { UNPROTECT(2); Rf_error("Sum of weights must be greater than 0"); }
+    validate_weights(w);                           /* :6-8 */
     const double *U = draw_uniforms(n);
-    const int st = bssm_resample_multinomial_r(get_ctx(n > LENGTH(w) ? n : LENGTH(w), 1), n, wp, LENGTH(w), U, INTEGER(out));
+    const int st = bssm_resample_multinomial_r(get_ctx(n > LENGTH(w) ? n : LENGTH(w), 1), n, REAL(w), LENGTH(w), U, INTEGER(out));
     UNPROTECT(2);
     check(st);
     return out;
@@ -132,6 +146,9 @@ SEXP _bayesSSM_pf_run(SEXP model, SEXP theta, SEXP y, SEXP obs_times, SEXP N, SE
     const int st = bssm_pf_run(get_ctx(c.num_particles, d), &c, &r);
     if (st != BSSM_OK) { UNPROTECT(3); check(st); }
     for (int i = 0; i <= T; i++) for (int k = 0; k < d; k++) REAL(se)[(size_t)k * (T + 1) + i] = se_rm[(size_t)i * d + k];   /* R matrices are column-major */
+    /* degenerate early return with a matrix state estimate: the rows never reached keep matrix(NA, ...)'s NA
+     * (R/particle_filter_core.R:90-95,189-202); the C ABI marks them NaN, R's missing value is NA_real_ */
+    if (early > 0 && d > 1) for (int i = early; i <= T; i++) for (int k = 0; k < d; k++) REAL(se)[(size_t)k * (T + 1) + i] = NA_REAL;
     SEXP out = PROTECT(Rf_allocVector(VECSXP, 5));
     SET_VECTOR_ELT(out, 0, se); SET_VECTOR_ELT(out, 1, ess);
     SET_VECTOR_ELT(out, 2, Rf_ScalarReal(ll)); SET_VECTOR_ELT(out, 3, llh);

@@ -196,3 +196,22 @@ def test_r_glue_file_binds_declared_symbols():
     for name in ("multinomial", "stratified", "systematic"):
         assert re.search(r'\{"_bayesSSM_resample_%s_cpp",\s+\(DL_FUNC\)&_bayesSSM_resample_%s_cpp, 2\}' % (name, name), glue)
     assert "R_registerRoutines(dll, NULL, CallEntries, NULL, NULL)" in glue and "R_useDynamicSymbols(dll, FALSE)" in glue
+
+
+def test_r_glue_compiles_against_api_stub():
+    """Compile hygiene only (NOT parity evidence): `gcc -fsyntax-only` type-checks r/bayesssm_amd_glue.c against a
+    declarations-only stand-in for the R API names it uses (tests/harness/r_api_stub/) and the real include/bayesssm_amd.h.
+    Also pins the order the reference has in all three entry points: validation before any draw
+    (src/resampling.cpp:6-8,17-23,44-50 precede :11,:28,:55)."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
+                        "-Werror=int-conversion", "-fsyntax-only", "-I" + os.path.join(root, "tests", "harness", "r_api_stub"),
+                        "-I" + os.path.join(root, "include"), os.path.join(root, "r", "bayesssm_amd_glue.c")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    glue = open(os.path.join(root, "r", "bayesssm_amd_glue.c")).read()
+    for name in ("systematic", "stratified", "multinomial"):
+        body = re.search(r"SEXP _bayesSSM_resample_%s_cpp\(.*?\n}\n" % name, glue, re.S).group(0)
+        assert 0 < body.index("validate_weights(w)") < body.index("draw_uniforms("), name

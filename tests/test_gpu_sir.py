@@ -100,3 +100,31 @@ def test_sir_c4_size_and_pmmh(B, ctx):
     th = ch["theta_chain"][40:]
     assert 0.05 < ch["accepted"] / 120 < 0.98
     assert 0.2 < th[:, 0].mean() < 0.9 and 0.05 < th[:, 1].mean() < 0.5
+
+
+def test_sir_degenerate_early_return_keeps_na_rows(B, ctx, oracle):
+    """all(log_weights < -1e8) at observation 3 (R/particle_filter_core.R:189-202) with a matrix state estimate: the rows
+    never reached keep matrix(NA, out_steps, d)'s NA (:90-95) -- NaN at the C ABI -- on the multi-launch path, in the
+    batched kernel and in the oracle alike; ess / loglike_history keep numeric()'s zeros."""
+    rng = np.random.default_rng(8)
+    T, N = 6, 2000
+    ys = _simulate(rng, T)
+    ys[2] = 1e9                                            # dpois(1e9, i <= 500, log = TRUE) < -1e8 for every particle
+    m = B.models.sir()
+    ur = rng.random((T, N))
+    res = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm="SISR",
+                             resample_fn="stratified", draws={"u_res": ur}, seed=4, stream=1, ctx=ctx,
+                             lambda_=THETA[0], gamma=THETA[1])
+    ref = oracle.pf_run("sir", [THETA[0], THETA[1], 500, 430, 70], ys, N, None, None, ur, resample_algorithm="SISR",
+                        resample_fn="stratified", seed=4, stream=1)
+    assert ref["early_return_step"] == 3 and res["_extras"]["early_return_step"] == 3
+    assert res["loglike"] == -np.inf and "resample_algorithm" not in res
+    for r in (res, ref):
+        assert np.isfinite(r["state_est"][:3]).all() and np.isnan(r["state_est"][3:]).all()
+        assert (r["ess"][3:] == 0).all() and (np.asarray(r["loglike_history"])[3:] == 0).all()
+    np.testing.assert_allclose(res["state_est"][:3], ref["state_est"][:3], rtol=1e-9)
+    bt = B.bootstrap_filter_batch(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn,
+                                  [[THETA[0], THETA[1], 500, 430, 70]], seeds=[4], streams=[1],
+                                  resample_algorithm="SISR", resample_fn="stratified", ctx=ctx)
+    assert int(bt["early_return_step"][0]) == 3
+    assert np.isfinite(bt["state_est"][0][:3]).all() and np.isnan(bt["state_est"][0][3:]).all()
