@@ -46,6 +46,35 @@ constexpr int MAXB = 2048;       // max scan workgroups  => N <= 2^22 per filter
 // The bulk stores of a kernel (resampled particles, normalised weights) are streaming stores: the data is next read by another
 // kernel, from other XCDs, and a kernel ends when its stores have drained -- non-temporal ones drain ~0.5 us sooner per kernel.
 typedef double v2d_nt __attribute__((ext_vector_type(2)));
+// Build-time store flavour of the three bulk outputs (experiment switches; make ST_W=.. ST_X=.. ST_S=..):
+//   0 = non-temporal (streaming), 1 = sc1 write-through (leaves nothing dirty in L2 for the end-of-kernel write-back), 2 = plain
+#ifndef BSSM_ST_W
+#define BSSM_ST_W 0
+#endif
+#ifndef BSSM_ST_X
+#define BSSM_ST_X 1
+#endif
+#ifndef BSSM_ST_S
+#define BSSM_ST_S 2
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int F>
+__device__ __forceinline__ void bulk_store16(double* p /* 16-byte aligned */, double a, double b)
+{
+    if constexpr (F == 0) { v2d_nt q; q.x = a; q.y = b; __builtin_nontemporal_store(q, reinterpret_cast<v2d_nt*>(p)); }
+    else if constexpr (F == 1) {
+        const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+        u32x4_t v; v.x = (unsigned)ua; v.y = (unsigned)(ua >> 32); v.z = (unsigned)ub; v.w = (unsigned)(ub >> 32);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+    } else { double2 q; q.x = a; q.y = b; *reinterpret_cast<double2*>(p) = q; }
+}
+template <int F>
+__device__ __forceinline__ void bulk_store8(double* p, double a)
+{
+    if constexpr (F == 0) __builtin_nontemporal_store(a, p);
+    else if constexpr (F == 1) __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = a;
+}
 constexpr int MODE_W = 0;        // terms are the weights themselves        (total = sum(w))
 constexpr int MODE_P = 1;        // terms are prob = w / total              (cum = cumsum(prob))
 
@@ -427,7 +456,7 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
             else normal_pair(ns.key, ns.purpose, ns.call, 0, (uint32_t)(j >> 1), z0, z1);
             x0 = Model<MODEL>::transition(x0, z0, par);
             x1 = Model<MODEL>::transition(x1, z1, par);
-            if (two) { double2 q; q.x = x0; q.y = x1; *reinterpret_cast<double2*>(xout + j) = q; }
+            if (two) bulk_store16<BSSM_ST_S>(xout + j, x0, x1);
             else xout[j] = x0;
         }
         if (WEIGHT) {
@@ -1243,7 +1272,7 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
         if (j0 + EL <= nw || (LIT && j0 < nw)) {             // (LIT: the partly filled lane stores its zero padding too -- the in-order pass reads whole lanes)
             double2* p2 = reinterpret_cast<double2*>(f.w_out + j0);
 #pragma unroll
-            for (int k = 0; k < EL / 2; k++) { v2d_nt q2; q2.x = v[2 * k]; q2.y = v[2 * k + 1]; __builtin_nontemporal_store(q2, reinterpret_cast<v2d_nt*>(p2 + k)); }
+            for (int k = 0; k < EL / 2; k++) bulk_store16<BSSM_ST_W>(reinterpret_cast<double*>(p2 + k), v[2 * k], v[2 * k + 1]);
         } else {
 #pragma unroll
             for (int k = 0; k < EL; k++) if (j0 + k < nw) f.w_out[j0 + k] = v[k];
@@ -2148,7 +2177,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
 #pragma unroll
                 for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; xv[r] = (i < Te) ? lx[i - Tb] : 0.0; }
 #pragma unroll
-                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; if (i < Te) { if (!STEP) __builtin_nontemporal_store(xv[r], a.xdst + i); acc0 += xv[r] * invN; } }
+                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; if (i < Te) { if (!STEP) bulk_store8<BSSM_ST_X>(a.xdst + i, xv[r]); acc0 += xv[r] * invN; } }
                 if constexpr (STEP) {
                     // the next observation's transition + weight on the staged particles, a PAIR of outputs per lane (the
                     // generator gives two normals per block, keyed by the pair's index -- exactly k_step's arithmetic);
