@@ -1091,6 +1091,128 @@ __device__ __forceinline__ Rec pure_to_rec(const Pure& p, uint64_t base, long lo
     return r;
 }
 
+// Where a block's record of a pass goes: the planes in HBM that the next kernel's workgroups read (GlobalRecSink), or
+// wherever a fused kernel publishes it.  `literal`: the in-order fallback of a block that starts from exact +0.
+template <int MODE>
+struct GlobalRecSink {
+    BlockRec* brec; SideList* sides; int bidx, bstride;
+    const double* w; long long nw; double total; long long b0; DevState* st;
+    __device__ __forceinline__ void rec(const BlockRec& br) const { store_brec(brec, bidx, br, bstride); }
+    __device__ __forceinline__ void side(int k, const SideEntry& e) const { this->side_list()[k] = e; }
+    __device__ __forceinline__ SideEntry* side_list() const { return sides[bidx].e; }
+    __device__ __forceinline__ void literal(uint64_t* tin, uint64_t cin) const { block_literal<MODE>(tin, cin, w, nw, total, b0, st); }
+};
+
+// The block's record for the grid-level resolve, from its scan (see k_local below for the four cases).
+template <int MODE, int STAMPCOL, class Sink>
+__device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, const BlockScan& bs, const double (&v)[EL], const double a_in,
+                                                  const int lim, DevState* st, const int dbg, const bool stamper, const Sink& sink)
+{
+    const int t = threadIdx.x;
+    (void)dbg; (void)stamper;
+    const uint64_t hb0 = d2b(a_in) & ~3ull;
+    if (a_in == 0.0) {
+        // exact incoming state (+0): resolve now and publish the exact outgoing state
+        uint64_t ent;
+        bool good = block_resolve<MODE>(sm, bs, 0ull, lim, nullptr, 0, 1.0, 0, ent);
+        if (!good) { sink.literal(tin, 0ull); ent = tin[t]; }
+        if (t == NT - 1) {
+            double c = b2d(ent);
+#pragma unroll
+            for (int k = 0; k < EL; k++) c = c + v[k];
+            BlockRec br; br.prefix = rec_abs(d2b(c)); br.tail_from = NT; br.nside = 0;
+            sink.rec(br);
+        }
+        return;
+    }
+    // validity windows of segment 0 (lanes before the first boundary) and of the last segment when nb == 1
+    int fb = NT;
+    if (bs.nb > 0) {                       // (block-uniform; the typical block has no boundary lane and skips three barriers)
+        if (t == 0) sm.first_bnd = NT;
+        __syncthreads();
+        if (bs.isb && bs.seg == 0) sm.first_bnd = t;
+        __syncthreads();
+        fb = sm.first_bnd;
+        if (t == fb + 1) sm.seg1_base = bs.leaf.base;
+        __syncthreads();
+    }
+    long long mn[2] = {(1ll << 40), (1ll << 40)}, mx[2] = {-(1ll << 40), -(1ll << 40)};
+    if (!bs.isb && bs.seg <= 1) {
+        const uint64_t sb = (bs.seg == 0) ? hb0 : (sm.seg1_base & ~3ull);
+        const long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
+        const long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
+        const long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
+        if (bs.seg == 0) { mn[0] = lo_; mx[0] = hi_; } else { mn[1] = lo_; mx[1] = hi_; }   // no runtime index: keeps mn/mx in registers
+    }
+    block_minmax2(sm, mn, mx);
+    BSSM_STAMP(st, dbg, 2, STAMPCOL, stamper);
+    // segment-0 prefix record: lanes [0, fb)
+    if (bs.nb == 0) {
+        if (t == NT - 1) {
+            BlockRec br; br.prefix = pure_to_rec(bs.last_seg, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
+            br.tail_from = NT; br.nside = 0; sink.rec(br);
+        }
+        return;
+    }
+    bool done1 = false;
+    if (t == fb) {
+        // bs.exc of the first boundary lane = composite of segment 0
+        Rec pre = (fb == 0) ? rec_identity(hb0) : pure_to_rec(bs.exc, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
+        BlockRec br;
+        if (bs.nb == 1 && bs.leaf.kind == REC_X1) {
+            Rec r = rec_compose(pre, bs.leaf);
+            if (fb < NT - 1) {
+                const Rec post = pure_to_rec(bs.last_seg, sm.seg1_base, -(long long)lim - mn[1] + 4, (long long)lim - mx[1] - 4);
+                r = rec_compose(r, post);
+            }
+            if (r.kind != REC_HARD) { br.prefix = r; br.tail_from = NT; br.nside = 0; sink.rec(br); done1 = true; }
+        }
+        if (!done1) {
+            br.prefix = pre;
+            if (bs.nb <= MAXBND) { br.tail_from = NT; br.nside = bs.nb; }     // side list below
+            else { br.tail_from = fb; br.nside = 0; }                          // too many: literal tail
+            sink.rec(br);
+            atomicAdd((unsigned long long*)&st->stat_hard_blocks, 1ull);
+        }
+        sm.fail = done1 ? 1 : 0;      // reuse as "record complete" flag for the block
+    }
+    __syncthreads();
+    if (sm.fail || bs.nb > MAXBND) return;
+    // ---- side list: every boundary leaf + the PURE segment after it, with that segment's window ----
+    for (int k = t; k <= MAXBND; k += NT) { sm.smin[k] = 0x7fffffff; sm.smax[k] = -0x7fffffff; }
+    // the first lane of a segment (the lane after boundary seg-1) publishes the segment's hypothesis base
+    if (!bs.isb && bs.seg >= 1 && t == sm.bnd_lane[bs.seg - 1] + 1) sm.segbase[bs.seg] = bs.leaf.base;
+    __syncthreads();
+    if (!bs.isb && bs.seg >= 1) {
+        const uint64_t sb = sm.segbase[bs.seg] & ~3ull;
+        long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
+        long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
+        long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
+        const long long C = (1ll << 30);
+        lo_ = lo_ < -C ? -C : (lo_ > C ? C : lo_); hi_ = hi_ < -C ? -C : (hi_ > C ? C : hi_);
+        atomicMin(&sm.smin[bs.seg], (int)lo_);
+        atomicMax(&sm.smax[bs.seg], (int)hi_);
+    }
+    __syncthreads();
+    if (bs.isb) {
+        const int k = bs.seg;
+        SideEntry e;
+        e.leaf = bs.leaf;
+        const Pure post = (k + 1 < bs.nb) ? sm.bnd_excl[k + 1] : bs.last_seg;
+        e.d0 = post.d0; e.d1 = post.d1;
+        const bool has_post = (sm.smin[k + 1] != 0x7fffffff);
+        e.post_base = has_post ? (sm.segbase[k + 1] & ~3ull) : 0ull;
+        const long long lo = has_post ? (-(long long)lim - (long long)sm.smin[k + 1] + 4) : -(1ll << 30);
+        const long long hi = has_post ? ((long long)lim - (long long)sm.smax[k + 1] - 4) : (1ll << 30);
+        e.lo = (int32_t)(lo < -(1ll << 30) ? -(1ll << 30) : (lo > (1ll << 30) ? (1ll << 30) : lo));
+        e.hi = (int32_t)(hi < -(1ll << 30) ? -(1ll << 30) : (hi > (1ll << 30) ? (1ll << 30) : hi));
+        e.lane = t; e.pad = has_post ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < EL; q++) e.terms[q] = v[q];     // so the resolver can re-run this leaf without chasing w[]
+        sink.side(k, e);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_local: the block's record for the grid-level resolve.
 //   no boundary            -> PURE record (d0,d1) + validity window
@@ -1302,106 +1424,10 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
     block_scan<MODE>(sm, v, a_in, lim, bs);
     __syncthreads();
     BSSM_STAMP(st, dbg, 2, FROM_LW ? 10 : 2, stamper);
-    const uint64_t hb0 = d2b(a_in) & ~3ull;
-    if (a_in == 0.0) {
-        // exact incoming state (+0): resolve now and publish the exact outgoing state
-        uint64_t ent;
-        bool good = block_resolve<MODE>(sm, bs, 0ull, lim, w, nw, total, b0, ent);
-        if (!good) { block_literal<MODE>(tin, 0ull, w, nw, total, b0, st); ent = tin[t]; }
-        if (t == NT - 1) {
-            double c = b2d(ent);
-#pragma unroll
-            for (int k = 0; k < EL; k++) c = c + v[k];
-            BlockRec br; br.prefix = rec_abs(d2b(c)); br.tail_from = NT; br.nside = 0;
-            store_brec(brec, bidx, br, bstride);
-        }
-        return;
-    }
-    // validity windows of segment 0 (lanes before the first boundary) and of the last segment when nb == 1
-    int fb = NT;
-    if (bs.nb > 0) {                       // (block-uniform; the typical block has no boundary lane and skips three barriers)
-        if (t == 0) sm.first_bnd = NT;
-        __syncthreads();
-        if (bs.isb && bs.seg == 0) sm.first_bnd = t;
-        __syncthreads();
-        fb = sm.first_bnd;
-        if (t == fb + 1) sm.seg1_base = bs.leaf.base;
-        __syncthreads();
-    }
-    long long mn[2] = {(1ll << 40), (1ll << 40)}, mx[2] = {-(1ll << 40), -(1ll << 40)};
-    if (!bs.isb && bs.seg <= 1) {
-        const uint64_t sb = (bs.seg == 0) ? hb0 : (sm.seg1_base & ~3ull);
-        const long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
-        const long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
-        const long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
-        if (bs.seg == 0) { mn[0] = lo_; mx[0] = hi_; } else { mn[1] = lo_; mx[1] = hi_; }   // no runtime index: keeps mn/mx in registers
-    }
-    block_minmax2(sm, mn, mx);
-    BSSM_STAMP(st, dbg, 2, FROM_LW ? 11 : 3, stamper);
-    // segment-0 prefix record: lanes [0, fb)
-    if (bs.nb == 0) {
-        if (t == NT - 1) {
-            BlockRec br; br.prefix = pure_to_rec(bs.last_seg, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
-            br.tail_from = NT; br.nside = 0; store_brec(brec, bidx, br, bstride);
-        }
-        return;
-    }
-    bool done1 = false;
-    if (t == fb) {
-        // bs.exc of the first boundary lane = composite of segment 0
-        Rec pre = (fb == 0) ? rec_identity(hb0) : pure_to_rec(bs.exc, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
-        BlockRec br;
-        if (bs.nb == 1 && bs.leaf.kind == REC_X1) {
-            Rec r = rec_compose(pre, bs.leaf);
-            if (fb < NT - 1) {
-                const Rec post = pure_to_rec(bs.last_seg, sm.seg1_base, -(long long)lim - mn[1] + 4, (long long)lim - mx[1] - 4);
-                r = rec_compose(r, post);
-            }
-            if (r.kind != REC_HARD) { br.prefix = r; br.tail_from = NT; br.nside = 0; store_brec(brec, bidx, br, bstride); done1 = true; }
-        }
-        if (!done1) {
-            br.prefix = pre;
-            if (bs.nb <= MAXBND) { br.tail_from = NT; br.nside = bs.nb; }     // side list below
-            else { br.tail_from = fb; br.nside = 0; }                          // too many: literal tail
-            store_brec(brec, bidx, br, bstride);
-            atomicAdd((unsigned long long*)&st->stat_hard_blocks, 1ull);
-        }
-        sm.fail = done1 ? 1 : 0;      // reuse as "record complete" flag for the block
-    }
-    __syncthreads();
-    if (sm.fail || bs.nb > MAXBND) return;
-    // ---- side list: every boundary leaf + the PURE segment after it, with that segment's window ----
-    for (int k = t; k <= MAXBND; k += NT) { sm.smin[k] = 0x7fffffff; sm.smax[k] = -0x7fffffff; }
-    // the first lane of a segment (the lane after boundary seg-1) publishes the segment's hypothesis base
-    if (!bs.isb && bs.seg >= 1 && t == sm.bnd_lane[bs.seg - 1] + 1) sm.segbase[bs.seg] = bs.leaf.base;
-    __syncthreads();
-    if (!bs.isb && bs.seg >= 1) {
-        const uint64_t sb = sm.segbase[bs.seg] & ~3ull;
-        long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
-        long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
-        long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
-        const long long C = (1ll << 30);
-        lo_ = lo_ < -C ? -C : (lo_ > C ? C : lo_); hi_ = hi_ < -C ? -C : (hi_ > C ? C : hi_);
-        atomicMin(&sm.smin[bs.seg], (int)lo_);
-        atomicMax(&sm.smax[bs.seg], (int)hi_);
-    }
-    __syncthreads();
-    if (bs.isb) {
-        const int k = bs.seg;
-        SideEntry& e = side[bidx].e[k];
-        e.leaf = bs.leaf;
-        const Pure post = (k + 1 < bs.nb) ? sm.bnd_excl[k + 1] : bs.last_seg;
-        e.d0 = post.d0; e.d1 = post.d1;
-        const bool has_post = (sm.smin[k + 1] != 0x7fffffff);
-        e.post_base = has_post ? (sm.segbase[k + 1] & ~3ull) : 0ull;
-        const long long lo = has_post ? (-(long long)lim - (long long)sm.smin[k + 1] + 4) : -(1ll << 30);
-        const long long hi = has_post ? ((long long)lim - (long long)sm.smax[k + 1] - 4) : (1ll << 30);
-        e.lo = (int32_t)(lo < -(1ll << 30) ? -(1ll << 30) : (lo > (1ll << 30) ? (1ll << 30) : lo));
-        e.hi = (int32_t)(hi < -(1ll << 30) ? -(1ll << 30) : (hi > (1ll << 30) ? (1ll << 30) : hi));
-        e.lane = t; e.pad = has_post ? 1 : 0;
-#pragma unroll
-        for (int q = 0; q < EL; q++) e.terms[q] = v[q];     // so the resolver can re-run this leaf without chasing w[]
-    }
+    GlobalRecSink<MODE> sink; sink.brec = brec; sink.sides = side; sink.bidx = bidx; sink.bstride = bstride;
+    sink.w = w; sink.nw = nw; sink.total = total; sink.b0 = b0; sink.st = st;
+    if constexpr (FROM_LW) block_record_tail<MODE, 11>(sm, tin, bs, v, a_in, lim, st, dbg, stamper, sink);
+    else block_record_tail<MODE, 3>(sm, tin, bs, v, a_in, lim, st, dbg, stamper, sink);
 }
 
 
@@ -1976,7 +2002,8 @@ struct ApplyArgs {
 // (arguments and results by value: taking the caller's accumulators or its argument block by reference would push them
 // into scratch memory on the hot path as well)
 __device__ __attribute__((noinline)) double2 expand_by_search(const int* Tl, int* anc, const double* xsrc, double* xdst, int dim, long long xstride,
-                                                              const double* auxsrc, double* auxdst, long long b0, int Tb, int Te, double invN)
+                                                              const double* auxsrc, double* auxdst, long long b0, int Tb, int Te, double invN,
+                                                              const double* xloc = nullptr /* the block's own particles in LDS, [dim][EB] */)
 {
     double acc0 = 0.0, acc1 = 0.0;
     for (int i = Tb + (int)threadIdx.x; i < Te; i += NT) {
@@ -1989,9 +2016,9 @@ __device__ __attribute__((noinline)) double2 expand_by_search(const int* Tl, int
         const long long src = b0 + lo;
         if (anc) anc[i] = (int)(src + 1);
         if (xdst) {
-            const double x0 = xsrc[src];
+            const double x0 = xloc ? xloc[lo] : xsrc[src];
             xdst[i] = x0; acc0 += x0 * invN;
-            if (dim > 1) { const double x1 = xsrc[xstride + src]; xdst[xstride + i] = x1; acc1 += x1 * invN; }
+            if (dim > 1) { const double x1 = xloc ? xloc[EB + lo] : xsrc[xstride + src]; xdst[xstride + i] = x1; acc1 += x1 * invN; }
         }
         if (auxdst) auxdst[i] = auxsrc[src];
     }
@@ -2001,78 +2028,21 @@ __device__ __attribute__((noinline)) double2 expand_by_search(const int* Tl, int
 
 constexpr int CAPX = 3072;       // outputs a block can stage in LDS for the coalesced store (it owns ~EB of them)
 
-// LEAN (scalar state, no auxiliary log-weights to carry; grids that run several rounds of workgroups per CU): the registers of the
-// second state component and of the auxiliary values are not allocated, and CAP < CAPX outputs are staged -- together four
-// workgroups fit a CU instead of three (112 VGPRs, 40.7 KiB LDS).
-template <int KIND, bool LIT = false, class Pro = NoResolve, bool STEP = false, int CAP = CAPX, bool LEAN = false>
-__device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
-                                            const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [nstage][CAPX] or nullptr */, const int nstage = 0,
-                                            const Pro pro = Pro())
+// The second half of the expansion kernel's body: from every lane's exact incoming state `ent` (and its EL terms v[] = prob)
+// to the exact cum_sum, the output counts, the ancestors and particles[indices, ].  xs0 / xs1 / axs: the particles (and
+// auxiliary log-weights) of the lane's EXPANSION elements  wave * 64 * EL + 64 k + lane  (lane-interleaved, see apply_block).
+template <int KIND, bool STEP, int CAP, bool LEAN>
+__device__ __forceinline__ void apply_tail(SegSmem& sm, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk, const ApplyArgs& a, DevState* st,
+                                           double* lx, const int nstage, const double (&v)[EL], const uint64_t ent,
+                                           const double (&xs0)[EL], const double (&xs1)[EL], const double (&axs)[EL],
+                                           const int call, const UniformSrc& us, const double Usys, const int dbg, const bool stamper,
+                                           const double* xloc = nullptr /* the block's own particles in LDS ([dim][EB]) when they are not in a.xsrc */)
 {
     const int t = threadIdx.x;
     const bool d2 = !LEAN && (a.dim > 1), aux = !LEAN && (a.auxdst != nullptr);
     const long long b0 = (long long)bidx * EB;
-    // run-state words and this lane's terms are fetched together (one memory round trip, not two)
-    const int s_dead = st->dead, s_do = st->do_resample, call = st->cur_call, dbg = st->debug_stop;
-    const uint32_t s_flags = st->flags;
-    const double total = b2d(st->total_bits);
-    double v[EL];
-    load_terms<MODE_W>(a.w, a.nw, 1.0, b0 + (long long)t * EL, v);
-    // The particles travel with the elements that own them: the common expansion path stores them straight to the
-    // outputs their elements own, with no dependent gather.  For the expansion a lane holds the elements
-    // wave * 64 * EL + 64 k + lane (k = 0..EL-1) -- lane-interleaved, NOT the EL consecutive elements its terms cover:
-    // neighbouring lanes then write neighbouring outputs.  (With consecutive elements per lane the lanes' output
-    // positions were ~EL apart and the 8-byte LDS stores ran into 8-way bank conflicts: that stage took 9k of the kernel's
-    // 19k cycles, profiles/r02_a_stage_stamps_typical_block.txt.)
-    const int ebase = (t >> 6) * (64 * EL) + (t & 63);       // element (within the block) of k = 0
-    double xs0[EL], xs1[EL], axs[EL];
-#pragma unroll
-    for (int k = 0; k < EL; k++) { xs0[k] = 0.0; xs1[k] = 0.0; axs[k] = 0.0; }
-    if (KIND != 2) {
-#pragma unroll
-        for (int k = 0; k < EL; k++) {
-            const long long j = b0 + ebase + 64 * k;
-            if (j < a.nw) {
-                if (a.xdst) { xs0[k] = a.xsrc[j]; if (d2) xs1[k] = a.xsrc[a.xstride + j]; }
-                if (aux) axs[k] = a.auxsrc[j];
-            }
-        }
-    }
-    const double a_in_p = a.ain_p[bidx];
-    const uint64_t cin_ld = Pro::active ? 0ull : a.cin[bidx];
-    if (s_dead || !s_do || s_flags) return;
-    // (INRES: every workgroup resolves the MODE_P pass for itself -- its own exact incoming state -- while its weight and
-    //  particle loads are in flight; the resolve's scratch borrows the staging area, which is not in use yet)
-    const uint64_t cinb = Pro::active ? pro() : cin_ld;
-    if (Pro::active) __syncthreads();
-    if (t == 0) sm.big = 0;
-    // the uniform(s) of this resample call (systematic: one draw; computed here, under the load latency)
-    UniformSrc us;
-    us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
-    us.key = a.key; us.call = (uint32_t)call;
-    const double Usys = (KIND == 1) ? us(0) : 0.0;
-    const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0)); (void)stamper;
-    BSSM_STAMP(st, dbg, 3, 0, stamper);
-#pragma unroll
-    for (int k = 0; k < EL; k++) v[k] = v[k] / total;                  // prob = weights / total (src/resampling.cpp:24,51)
-    BSSM_STAMP(st, dbg, 3, 1, stamper && v[0] >= 0.0);
-    uint64_t ent;
-    if (LIT) {
-        // one block of few terms from exact +0: publish prob (zero beyond nw) in the not yet written destination buffer and add in order
-        double2* p2 = reinterpret_cast<double2*>(a.xdst + (long long)t * EL);
-#pragma unroll
-        for (int k = 0; k < EL / 2; k++) { double2 q2; q2.x = v[2 * k]; q2.y = v[2 * k + 1]; p2[k] = q2; }
-        __syncthreads();
-        block_literal_terms(tin, a.xdst, (int)a.nw);
-        ent = tin[t];
-    } else {
-        BlockScan bs;
-        block_scan<MODE_P>(sm, v, a_in_p, a.lim, bs);
-        __syncthreads();
-        BSSM_STAMP(st, dbg, 3, 2, stamper);
-        const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
-        if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
-    }
+    const int ebase = (t >> 6) * (64 * EL) + (t & 63);
+    (void)nblk; (void)dbg; (void)stamper;
     BSSM_STAMP(st, dbg, 3, 3, stamper);
     // the reference chain itself, from the exact incoming state
     int Tk[EL];
@@ -2216,7 +2186,7 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
             }
         }
     } else {
-        const double2 r = expand_by_search(Tl, anc, a.xsrc, a.xdst, a.dim, a.xstride, a.auxsrc, a.auxdst, b0, Tb, Te, invN);
+        const double2 r = expand_by_search(Tl, anc, a.xsrc, a.xdst, a.dim, a.xstride, a.auxsrc, a.auxdst, b0, Tb, Te, invN, xloc);
         acc0 = r.x; acc1 = r.y;
         if constexpr (STEP) step_in_place = true;
     }
@@ -2248,6 +2218,82 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         if (t == 0) { a.se_part[(long long)bidx * a.dim] = acc0; if (d2) a.se_part[(long long)bidx * a.dim + 1] = acc1; }
     }
     BSSM_STAMP(st, dbg, 3, 6, stamper);
+}
+
+
+// LEAN (scalar state, no auxiliary log-weights to carry; grids that run several rounds of workgroups per CU): the registers of the
+// second state component and of the auxiliary values are not allocated, and CAP < CAPX outputs are staged -- together four
+// workgroups fit a CU instead of three (112 VGPRs, 40.7 KiB LDS).
+template <int KIND, bool LIT = false, class Pro = NoResolve, bool STEP = false, int CAP = CAPX, bool LEAN = false>
+__device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 1] */, int* Tl /* [EB] */, int& Tbegin, const int bidx, const int nblk,
+                                            const ApplyArgs& a, DevState* st, double* lx = nullptr /* LDS [nstage][CAPX] or nullptr */, const int nstage = 0,
+                                            const Pro pro = Pro())
+{
+    const int t = threadIdx.x;
+    const bool d2 = !LEAN && (a.dim > 1), aux = !LEAN && (a.auxdst != nullptr);
+    const long long b0 = (long long)bidx * EB;
+    // run-state words and this lane's terms are fetched together (one memory round trip, not two)
+    const int s_dead = st->dead, s_do = st->do_resample, call = st->cur_call, dbg = st->debug_stop;
+    const uint32_t s_flags = st->flags;
+    const double total = b2d(st->total_bits);
+    double v[EL];
+    load_terms<MODE_W>(a.w, a.nw, 1.0, b0 + (long long)t * EL, v);
+    // The particles travel with the elements that own them: the common expansion path stores them straight to the
+    // outputs their elements own, with no dependent gather.  For the expansion a lane holds the elements
+    // wave * 64 * EL + 64 k + lane (k = 0..EL-1) -- lane-interleaved, NOT the EL consecutive elements its terms cover:
+    // neighbouring lanes then write neighbouring outputs.  (With consecutive elements per lane the lanes' output
+    // positions were ~EL apart and the 8-byte LDS stores ran into 8-way bank conflicts: that stage took 9k of the kernel's
+    // 19k cycles, profiles/r02_a_stage_stamps_typical_block.txt.)
+    const int ebase = (t >> 6) * (64 * EL) + (t & 63);       // element (within the block) of k = 0
+    double xs0[EL], xs1[EL], axs[EL];
+#pragma unroll
+    for (int k = 0; k < EL; k++) { xs0[k] = 0.0; xs1[k] = 0.0; axs[k] = 0.0; }
+    if (KIND != 2) {
+#pragma unroll
+        for (int k = 0; k < EL; k++) {
+            const long long j = b0 + ebase + 64 * k;
+            if (j < a.nw) {
+                if (a.xdst) { xs0[k] = a.xsrc[j]; if (d2) xs1[k] = a.xsrc[a.xstride + j]; }
+                if (aux) axs[k] = a.auxsrc[j];
+            }
+        }
+    }
+    const double a_in_p = a.ain_p[bidx];
+    const uint64_t cin_ld = Pro::active ? 0ull : a.cin[bidx];
+    if (s_dead || !s_do || s_flags) return;
+    // (INRES: every workgroup resolves the MODE_P pass for itself -- its own exact incoming state -- while its weight and
+    //  particle loads are in flight; the resolve's scratch borrows the staging area, which is not in use yet)
+    const uint64_t cinb = Pro::active ? pro() : cin_ld;
+    if (Pro::active) __syncthreads();
+    if (t == 0) sm.big = 0;
+    // the uniform(s) of this resample call (systematic: one draw; computed here, under the load latency)
+    UniformSrc us;
+    us.arr = a.u_base ? a.u_base + (long long)call * a.u_stride : nullptr;
+    us.key = a.key; us.call = (uint32_t)call;
+    const double Usys = (KIND == 1) ? us(0) : 0.0;
+    const bool stamper = (t == 0 && bidx == ((nblk > 100 && dbg != 98) ? 100 : 0)); (void)stamper;
+    BSSM_STAMP(st, dbg, 3, 0, stamper);
+#pragma unroll
+    for (int k = 0; k < EL; k++) v[k] = v[k] / total;                  // prob = weights / total (src/resampling.cpp:24,51)
+    BSSM_STAMP(st, dbg, 3, 1, stamper && v[0] >= 0.0);
+    uint64_t ent;
+    if (LIT) {
+        // one block of few terms from exact +0: publish prob (zero beyond nw) in the not yet written destination buffer and add in order
+        double2* p2 = reinterpret_cast<double2*>(a.xdst + (long long)t * EL);
+#pragma unroll
+        for (int k = 0; k < EL / 2; k++) { double2 q2; q2.x = v[2 * k]; q2.y = v[2 * k + 1]; p2[k] = q2; }
+        __syncthreads();
+        block_literal_terms(tin, a.xdst, (int)a.nw);
+        ent = tin[t];
+    } else {
+        BlockScan bs;
+        block_scan<MODE_P>(sm, v, a_in_p, a.lim, bs);
+        __syncthreads();
+        BSSM_STAMP(st, dbg, 3, 2, stamper);
+        const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
+        if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
+    }
+    apply_tail<KIND, STEP, CAP, LEAN>(sm, Tl, Tbegin, bidx, nblk, a, st, lx, nstage, v, ent, xs0, xs1, axs, call, us, Usys, dbg, stamper);
 }
 
 
