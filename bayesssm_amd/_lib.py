@@ -95,6 +95,8 @@ def load():
     lib.bssm_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
     lib.bssm_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.bssm_ctx_get_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bssm_ctx_fused_stats.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bssm_ctx_fused_stamps.argtypes = [C.c_void_p, C.c_void_p]
     lib.bssm_ctx_get_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bssm_resample_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
@@ -127,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_ctx_set_option", "bssm_ctx_get_stamps", "bssm_pmmh_chain",
     "bssm_resample_multinomial_r",
     "bssm_pf_run_batch", "bssm_pf_batch_max_particles", "bssm_pmmh_chains_batch", "bssm_pmmh_chain_draws",
-    "bssm_pf_run_sharded", "bssm_pf_weigh_resample",
+    "bssm_pf_run_sharded", "bssm_pf_weigh_resample", "bssm_ctx_fused_stats", "bssm_ctx_fused_stamps",
 ]
 
 
@@ -159,11 +161,17 @@ class Context:
     def synchronize(self):
         check(load().bssm_ctx_synchronize(self._h))
 
-    OPTIONS = {"record_window": 1, "batch_literal_max": 2, "stage_expansion": 3, "inkernel_resolve": 4, "debug_stop": 5, "fuse_step": 6, "renormalize": 7, "recompute_lw": 8}
+    OPTIONS = {"record_window": 1, "batch_literal_max": 2, "stage_expansion": 3, "inkernel_resolve": 4, "debug_stop": 5, "fuse_step": 6, "renormalize": 7, "recompute_lw": 8, "fused": 9, "fused_prefetch": 10}
 
     def set_option(self, name, value):
         """per-context test aid / A/B switch (include/bayesssm_amd.h BSSM_OPT_*)"""
         check(load().bssm_ctx_set_option(self._h, self.OPTIONS[name], int(value)))
+
+    def fused_stats(self):
+        """{runs, launches, stand_downs, timeouts} of the one-launch-per-observation path on this context"""
+        out = (C.c_longlong * 4)()
+        check(load().bssm_ctx_fused_stats(self._h, out))
+        return {"runs": out[0], "launches": out[1], "stand_downs": out[2], "timeouts": out[3]}
 
     def set_profile(self, enable):
         check(load().bssm_ctx_set_profile(self._h, 1 if enable else 0))

@@ -14,6 +14,8 @@
 #include <map>
 #include <algorithm>
 #include "kernels.hip.h"
+#include "fused.hip.h"
+#include <atomic>
 #include "../../include/bayesssm_amd.h"
 
 using namespace bssm;
@@ -61,6 +63,11 @@ struct bssm_ctx {
                                    // (off: measured slower -- 7 generator pairs per lane at 2 waves per SIMD cost the expansion kernel 7.7 us,
                                    //  the k_step launch they replace costs 11.2 us but the per-block partials still need a 5.4 us launch)
     int opt_debug_stop = 0;        // DEV builds: stage stamps (99 typical block, 98 head block, 97 batched kernel)
+    int opt_fused_prefetch = 0;    // fused path: the next observation's transition normals are drawn while the workgroups wait for the resolver
+    int opt_fused = 1;             // bootstrap filters on the scalar Gaussian-observation models, N <= 2^20: one launch per observation (fused.hip.h)
+    // fused path: workspace of the tagged records, launch counter (the tags), what happened
+    FusedWs* fz = nullptr; uint32_t fz_tag = 0; bool fz_ok = false;
+    long long fz_launches = 0, fz_runs = 0, fz_bails = 0, fz_timeouts = 0;
     // growable buffers
     std::map<std::string, std::pair<void*, size_t>> pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -72,6 +79,10 @@ struct bssm_ctx {
     std::vector<hipEvent_t> ev_pool;
     int last_device_status = 0;
 };
+
+// One fused run at a time per device (in this process): all workgroups of a fused launch must be resident together, and two
+// such launches from two contexts could each hold half of the chip.  A run that does not get the token takes the multi-launch path.
+static std::atomic<int> g_fused_busy[64];
 
 static int pool_get(bssm_ctx* c, const char* name, size_t bytes, void** out)
 {
@@ -165,6 +176,23 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
                             reinterpret_cast<const void*>(&k_apply<1, true, true>), reinterpret_cast<const void*>(&k_apply<1, false, true>)})
         if (e == hipSuccess) e = hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
     static_assert(sizeof(ResolveSmem) <= 3 * CAPX * sizeof(double), "the in-kernel resolve borrows k_apply's staging area");
+    if (e == hipSuccess) {
+        // fused path: workspace (zeroed once: the tags only grow), dynamic LDS, and the residency it rests on -- two workgroups
+        // per CU, every block of the largest grid resident at once
+        e = hipMalloc((void**)&c->fz, sizeof(FusedWs));
+        if (e == hipSuccess) e = hipMemsetAsync(c->fz, 0, sizeof(FusedWs), c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        int per_cu = 8, ncu = 0;
+        for (const void* fnp : {reinterpret_cast<const void*>(&k_obs<0, 0>), reinterpret_cast<const void*>(&k_obs<0, 1>),
+                                reinterpret_cast<const void*>(&k_obs<1, 0>), reinterpret_cast<const void*>(&k_obs<1, 1>)}) {
+            if (e == hipSuccess) e = hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FZ_DYN_LDS);
+            int nb = 0;
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fnp, NT, FZ_DYN_LDS);
+            per_cu = std::min(per_cu, nb);
+        }
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        c->fz_ok = (e == hipSuccess) && per_cu >= 1 && (long long)per_cu * ncu >= FZ_MAXB;
+    }
     if (e != hipSuccess) {
         g_err = std::string("bssm_ctx_create: ") + hipGetErrorString(e);
         bssm_ctx_destroy(c);
@@ -180,7 +208,7 @@ extern "C" void bssm_ctx_destroy(bssm_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->x0, c->x1, c->lw, c->w, c->auxlw, c->auxg, c->cum, c->pm, c->ps, c->pq, c->bsum, c->bsq,
-                    c->ain_w, c->ain_p, c->brec, c->brec_p, c->side, c->side_p, c->cin, c->st};
+                    c->ain_w, c->ain_p, c->brec, c->brec_p, c->side, c->side_p, c->cin, c->st, c->fz};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : c->pool) if (kv.second.first) (void)hipFree(kv.second.first);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -213,6 +241,8 @@ extern "C" int bssm_ctx_set_option(bssm_ctx* c, int option, int value)
         case BSSM_OPT_FUSE_STEP: c->opt_fuse_step = value; break;
         case BSSM_OPT_RECOMPUTE_LW: c->opt_recompute_lw = value ? 1 : 0; break;
         case BSSM_OPT_RENORMALIZE: c->opt_renormalize = value ? 1 : 0; break;
+        case BSSM_OPT_FUSED: c->opt_fused = value < 0 ? 0 : (value > 2 ? 2 : value); break;
+        case BSSM_OPT_FUSED_PREFETCH: c->opt_fused_prefetch = value ? 1 : 0; break;
         default: ARGFAIL("bssm_ctx_set_option: unknown option");
     }
     return BSSM_OK;
@@ -388,6 +418,7 @@ static void launch_scan_and_apply(bssm_ctx* c, const ResampleLaunch& r)
 
 static int flags_to_status(uint32_t f)
 {
+    f &= ~(FLAG_FUSED_BAIL | FLAG_FUSED_TIMEOUT);      // (not errors: the run is repeated on the multi-launch path)
     if (f & FLAG_NEGATIVE) return BSSM_ERR_NEGATIVE_WEIGHT;     // checked first, as the reference does
     if (f & FLAG_NONFINITE) { g_err = "weights contain NaN/Inf"; return BSSM_ERR_ARG; }
     if (f & FLAG_ZERO_SUM) return BSSM_ERR_ZERO_SUM;
@@ -581,7 +612,9 @@ static void launch_step_model(bssm_ctx* c, int model, bool trans, int weight, bo
     else launch_step_sir(c, trans, weight, subaux, x, N, B, par, y, ns);
 }
 
-extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* res)
+static constexpr int BSSM_RETRY_UNFUSED = -1000;     // internal: a fused run stood down, repeat it on the multi-launch path
+
+static int pf_run_impl(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* res, bool allow_fused)
 {
     if (!c || !cfg || !res) ARGFAIL("bssm_pf_run: NULL argument");
     const long long N = cfg->num_particles;
@@ -683,9 +716,18 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     }
     int ktrans = 0, prev_t = 0;
     bool stepped_ahead = false;
+    const double* z_ready = nullptr;      // fused path: the normals of the coming fused transition, drawn by the previous launch
     // bootstrap / resample-move filter on the Gaussian-observation models: k_step does not store the log-weights, k_weights
     // re-evaluates dnorm(y, x) on the particles (8 MB less written per observation at N = 2^20, the same 8 MB read)
     const bool relw = c->opt_recompute_lw && !apf && !sir && !c->opt_fuse_step;
+    // one launch per observation (fused.hip.h): bootstrap / resample-move filter, scalar Gaussian-observation model, stratified or
+    // systematic resampling, at most 512 blocks; the A/B and test switches that select other kernels keep the multi-launch path
+    // (grids of at most FZ_MINB blocks stay on the multi-launch path unless the option is 2: the fused launch's three in-launch hand-offs cost
+    //  ~10 us each whatever N is, the multi-launch kernels shrink with N: measured 52 vs 45 us per observation at N = 2^16 .. 2^18)
+    const bool fused = allow_fused && c->fz_ok && c->opt_fused && (B > FZ_MINB || c->opt_fused >= 2) && !apf && !sir && B <= FZ_MAXB && !c->sh_nloc && c->opt_renormalize &&
+                       !c->opt_fuse_step && c->opt_inkernel_resolve &&
+                       (cfg->resample_fn == BSSM_STRATIFIED || cfg->resample_fn == BSSM_SYSTEMATIC);
+    if (fused) c->fz_runs++;
     for (int i = 1; i <= T; i++) {                                                        // :123
         const int ot = cfg->obs_times ? cfg->obs_times[i - 1] : i;
         const int gap = ot - prev_t;                                                      // :124
@@ -696,6 +738,53 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         ResampleLaunch r;
         r.d_w = c->w; r.nw = N; r.n = (int)N; r.kind = cfg->resample_fn; r.d_u = (const double*)d_ur; r.u_stride = u_stride; r.key = key;
         r.d_anc = (int*)d_anc; r.anc_stride = N; r.d_cum = nullptr; r.dim = dim; r.xstride = N;
+        if (fused) {
+            for (int step = 1; step < gap; step++) { launch_step_model(c, cfg->model, true, 0, false, X0, N, B, par, yi, noise(ktrans)); ktrans++; }
+            FusedArgs g;
+            g.xin = X0; g.N = N; g.nblk = B; g.par = par; g.y = yi; g.trans = (gap >= 1) ? 1 : 0; g.ns = noise(gap >= 1 ? ktrans : 0);
+            if (gap >= 1) ktrans++;
+            g.obs_i = i; g.resample_algorithm = resample_algorithm; g.threshold = threshold;
+            g.ess_out = (double*)d_ess; g.llh_out = (double*)d_llh; g.resampled_out = (int*)d_resampled;
+            g.w_out = cfg->return_particles ? c->w : nullptr;
+            g.lim = c->opt_window > 0 ? c->opt_window : rec_window(N);
+            ApplyArgs& a = g.a;
+            a.w = c->w; a.nw = N; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = g.lim; a.n = (int)N;
+            a.u_base = (const double*)d_ur; a.u_stride = u_stride; a.key = key;
+            a.anc_out = (int*)d_anc; a.anc_stride = N; a.cum_out = nullptr;
+            a.xsrc = X0; a.xdst = X1; a.dim = 1; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr;
+            a.se_part = separt + (size_t)i * B * dim;
+            a.nstage = (c->opt_stage && !d_anc) ? 1 : 0; a.lead = 0; a.last = B - 1;
+            a.step_model = -1; a.step_par = par; a.step_y = 0; a.step_ns = g.ns; a.step_lw = nullptr;
+            g.ws = c->fz; g.tag = ++c->fz_tag;
+            // the normals of the NEXT fused transition are drawn inside this launch, in the time its workgroups wait for the resolver
+            // (device generator only; injected draws are arrays already); two buffers alternate (this launch reads one, fills the other)
+            g.znext = nullptr; g.znext_call = 0;
+            if (z_ready) { g.ns.arr = z_ready; z_ready = nullptr; }
+            if (!d_zt && i < T && c->opt_fused_prefetch) {
+                const int next_gap = (cfg->obs_times ? cfg->obs_times[i] : i + 1) - ot;
+                if (next_gap >= 1) {
+                    g.znext = (i & 1) ? c->auxlw : c->auxg; g.znext_call = (uint32_t)(ktrans + next_gap - 1);
+                    z_ready = g.znext;
+                }
+            }
+            c->fz_launches++;
+            const bool sysk = cfg->resample_fn == BSSM_SYSTEMATIC;
+            if (cfg->model == BSSM_MODEL_LG) { if (sysk) LAUNCH(c, "k_obs<systematic>", (k_obs<0, 1>), B, NT, FZ_DYN_LDS, g, c->st); else LAUNCH(c, "k_obs<stratified>", (k_obs<0, 0>), B, NT, FZ_DYN_LDS, g, c->st); }
+            else { if (sysk) LAUNCH(c, "k_obs<systematic>", (k_obs<1, 1>), B, NT, FZ_DYN_LDS, g, c->st); else LAUNCH(c, "k_obs<stratified>", (k_obs<1, 0>), B, NT, FZ_DYN_LDS, g, c->st); }
+            std::swap(X0, X1);
+            if (rmpf) {   // move every particle, then take the state estimate (:226-241)
+                double* se_row = separt + (size_t)i * B * dim;
+                const double* zm = d_zmv ? (const double*)d_zmv + (size_t)(i - 1) * N : nullptr;
+                const double* um = d_umv ? (const double*)d_umv + (size_t)(i - 1) * N : nullptr;
+                if (cfg->model == BSSM_MODEL_LG) LAUNCH(c, "k_move", k_move<0>, B, NT, 0, X0, N, par, yi, cfg->move_sd, zm, um, key, (uint32_t)i, se_row, c->st);
+                else LAUNCH(c, "k_move", k_move<1>, B, NT, 0, X0, N, par, yi, cfg->move_sd, zm, um, key, (uint32_t)i, se_row, c->st);
+            }
+            if (cfg->return_particles) {
+                LAUNCH(c, "k_record_history", k_record_history, (unsigned)((N + 255) / 256), 256, 0, X0, c->w, N, dim,
+                       (double*)d_ph + (size_t)i * N * dim, (double*)d_wh + (size_t)i * N, c->st);
+            }
+            continue;
+        }
         // gap transitions; the last one is fused with the weight evaluation unless APF  (:125-136)
         if (stepped_ahead) {
             // this observation's (single) transition and its log-weights were computed inside the previous observation's
@@ -770,6 +859,10 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     if (res->resampled && T > 0) HIPCHK(hipMemcpyAsync(res->resampled, d_resampled, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
+    if (fused && (h.flags & (FLAG_FUSED_BAIL | FLAG_FUSED_TIMEOUT))) {
+        if (h.flags & FLAG_FUSED_BAIL) c->fz_bails++; else c->fz_timeouts++;
+        return BSSM_RETRY_UNFUSED;
+    }
     if (res->device_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *res->device_ms = ms; }
     // ess[1] = 1 / sum(rep(1/N, N)^2)   (:106-107)
     res->ess[0] = 1.0 / (dN * ((1.0 / dN) * (1.0 / dN)));
@@ -794,6 +887,40 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
         HIPCHK(hipMemcpy(res->particles_history, d_ph, (size_t)rows * N * dim * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(res->weights_history, d_wh, (size_t)rows * N * 8, hipMemcpyDeviceToHost));
     }
+    return BSSM_OK;
+}
+
+extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* res)
+{
+    if (!c) ARGFAIL("bssm_pf_run: NULL argument");
+    // the fused path needs the device's token (one fused run at a time); without it the run takes the multi-launch path
+    const int dev = c->device & 63;
+    int expected = 0;
+    const bool token = c->opt_fused && c->fz_ok && g_fused_busy[dev].compare_exchange_strong(expected, 1);
+    int rc = pf_run_impl(c, cfg, res, token);
+    if (token) g_fused_busy[dev].store(0);
+    if (rc == BSSM_RETRY_UNFUSED) rc = pf_run_impl(c, cfg, res, false);      // deterministic: the same draws, the other kernels
+    return rc;
+}
+
+extern "C" int bssm_ctx_fused_stamps(bssm_ctx* c, long long* out /* [2][24] */)
+{   // DEV builds (make DEV=1): clock64() stage stamps of the last fused launch (typical worker, resolver); zeros otherwise
+    if (!c || !out || !c->fz) ARGFAIL("bssm_ctx_fused_stamps: NULL argument");
+    HIPCHK(hipMemcpy(out, c->fz->stamps, sizeof(c->fz->stamps), hipMemcpyDeviceToHost));
+    return BSSM_OK;
+}
+
+extern "C" int bssm_ctx_fused_pubt(bssm_ctx* c, long long* out /* [4][512] */)
+{
+    if (!c || !out || !c->fz) ARGFAIL("bssm_ctx_fused_pubt: NULL argument");
+    HIPCHK(hipMemcpy(out, c->fz->pubt, sizeof(c->fz->pubt), hipMemcpyDeviceToHost));
+    return BSSM_OK;
+}
+
+extern "C" int bssm_ctx_fused_stats(bssm_ctx* c, long long* out /* [4]: runs, launches, stand-downs (unsupported record), time-outs */)
+{
+    if (!c || !out) ARGFAIL("bssm_ctx_fused_stats: NULL argument");
+    out[0] = c->fz_runs; out[1] = c->fz_launches; out[2] = c->fz_bails; out[3] = c->fz_timeouts;
     return BSSM_OK;
 }
 

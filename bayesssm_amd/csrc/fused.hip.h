@@ -31,30 +31,46 @@ typedef unsigned long long fz_u64;
 #define BSSM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr int FZ_MAXB = 2 * NT;        // workers (blocks of EB particles): N <= 2^20
+constexpr int FZ_MINB = 384;           // grids up to this size stay on the multi-launch path by default (option fused = 2 forces the fused one)
 constexpr int FZ_KREC = 8;             // granules of a block record on the wire
 constexpr int FZ_KSIDE = (int)(sizeof(SideEntry) / 4);     // granules of a side entry
-constexpr int FZ_MAXSIDE = 8;          // side entries per block that travel in-launch (more: the run is repeated unfused)
+constexpr int FZ_NREP = 16;           // replicas of a result every worker reads (32 readers a line instead of 512)
+constexpr int FZ_MAXSIDE = 16;         // side entries per block that travel in-launch (more: the run is repeated unfused)
 constexpr uint32_t FLAG_FUSED_BAIL = 8u, FLAG_FUSED_TIMEOUT = 16u;
 constexpr uint32_t FZ_ST_DOIT = 1u, FZ_ST_DEAD = 2u, FZ_ST_STOP = 4u, FZ_ST_BAIL = 8u;     // status word of a result slot
 constexpr long long FZ_TIMEOUT_TICKS = 2000000ll;          // 20 ms of the 100 MHz wall clock
 
 struct FusedWs {
     fz_u64 e1[6][FZ_MAXB];                      // worker -> resolver: (max, sum exp, sum exp^2) of the block's log-weights
-    fz_u64 r1[FZ_MAXB][10];                     // resolver -> worker b: M, S, sum e^2, approximate prefix of the block, status
+    fz_u64 c1[FZ_NREP][16];                     // resolver -> all workers, replicated (worker b reads replica b % FZ_NREP): M, S, sum e^2, status
+    fz_u64 a1[2][FZ_MAXB];                      // resolver -> worker b: approximate prefix of the block (plane-major: the resolver's stores are contiguous)
     fz_u64 e2[FZ_KREC][FZ_MAXB];                // records of the sum(w) pass
-    fz_u64 r2[FZ_MAXB][4];                      // total (bit pattern), status
+    fz_u64 c2[FZ_NREP][16];                     // total (bit pattern), status
     fz_u64 e3[FZ_KREC][FZ_MAXB];                // records of the cumsum(w / total) pass
-    fz_u64 r3[FZ_MAXB][4];                      // the block's exact incoming state, status
+    fz_u64 c3[FZ_NREP][16];                     // status
+    fz_u64 a3[2][FZ_MAXB];                      // the block's exact incoming state
     fz_u64 side_w[FZ_MAXB][FZ_MAXSIDE][FZ_KSIDE];
     fz_u64 side_p[FZ_MAXB][FZ_MAXSIDE][FZ_KSIDE];
     // the resolver's private, plain copies: what the ordinary resolve code reads
-    BlockRec brec_priv[MAXB];                    // (four planes, BREC_STRIDE apart)
-    SideList side_priv[FZ_MAXB];
+    // (one set per pass: every address is written once and then read in a launch -- no line this CU's L1 may still hold from
+    //  the other pass)
+    BlockRec brec_priv[2][MAXB];                 // (four planes each, BREC_STRIDE apart)
+    SideList side_priv[2][FZ_MAXB];
+    long long stamps[2][24];
+    long long pubt[4][FZ_MAXB];                  // dev tool: wall clock (100 MHz) of every block's three publishes; [3][8..10] resolver's gather-done times                     // dev tool (make DEV=1): clock64() at the stages of a typical worker [0] / of the resolver [1], last launch
 };
+
+#ifdef BSSM_DEV_STAMPS
+#define FZ_STAMP(k) do { if (fz_stamper) g.ws->stamps[fz_row][k] = clock64(); } while (0)
+#else
+#define FZ_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ fz_u64 fz_gran(uint32_t tag, uint32_t v) { return ((fz_u64)tag << 32) | v; }
 __device__ __forceinline__ void fz_put(fz_u64* g, uint32_t tag, uint32_t v) { __hip_atomic_store(g, fz_gran(tag, v), BSSM_RLX_AGENT); }
 __device__ __forceinline__ void fz_put64(fz_u64* g, uint32_t tag, uint64_t v) { fz_put(g, tag, (uint32_t)v); fz_put(g + 1, tag, (uint32_t)(v >> 32)); }
+// (the two halves of a 64-bit value `stride` granules apart: plane-major results)
+__device__ __forceinline__ void fz_put64x(fz_u64* g, int stride, uint32_t tag, uint64_t v) { fz_put(g, tag, (uint32_t)v); fz_put(g + stride, tag, (uint32_t)(v >> 32)); }
 __device__ __forceinline__ fz_u64 fz_get(const fz_u64* g) { return __hip_atomic_load(g, BSSM_RLX_AGENT); }
 
 // ---- the block record on the wire: 8 words ------------------------------------------------------------------------
@@ -99,6 +115,20 @@ __device__ __forceinline__ bool fz_wait_slot(const fz_u64* slot, uint32_t tag, c
     for (unsigned spins = 0;; spins++) {
         bool ok = true;
         if (lane < NG) { const fz_u64 x = fz_get(slot + lane); ok = (uint32_t)(x >> 32) == tag; val = (uint32_t)x; }
+        if (__all(ok)) return true;
+        if ((spins & 31u) == 31u && clk.expired()) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// One wave waits for NG granules, lane i < NG polling the address it was given.
+template <int NG>
+__device__ __forceinline__ bool fz_wait_words(const fz_u64* mine, uint32_t tag, const FzClock& clk, uint32_t& val)
+{
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; spins++) {
+        bool ok = true;
+        if (lane < NG) { const fz_u64 x = fz_get(mine); ok = (uint32_t)(x >> 32) == tag; val = (uint32_t)x; }
         if (__all(ok)) return true;
         if ((spins & 31u) == 31u && clk.expired()) return false;
         __builtin_amdgcn_s_sleep(1);
@@ -161,6 +191,9 @@ struct FusedArgs {
     int lim;
     ApplyArgs a;                  // expansion: xdst, uniforms, ancestors, se_part, ...
     FusedWs* ws; uint32_t tag;    // launch number since the workspace was zeroed (never 0)
+    // the NEXT fused launch's transition normals, drawn here while this workgroup waits for the resolver (the generator is
+    // counter-based: a draw is a function of (key, call, particle slot)); nullptr: not wanted (last observation, injected draws)
+    double* znext; uint32_t znext_call;
 };
 
 struct FusedSmem {
@@ -175,12 +208,24 @@ struct FusedSmem {
 template <int NG>
 __device__ __forceinline__ bool fz_gather(const fz_u64* planes, int c0, int c1, uint32_t tag, const FzClock& clk, int* bail, uint32_t (&w0)[NG], uint32_t (&w1)[NG])
 {
+    // two blocks per thread (c0 even): ONE 16-byte sc1 load per plane fetches both granules; each 8-byte half is one store of its
+    // producer, checked by its own tag
+    const bool pair = ((c0 & 1) == 0) && (c0 + 1 < c1);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<fz_u64*>(planes), 0, NG * FZ_MAXB * 8, 0x00020000);
     for (unsigned spins = 0;; spins++) {
         bool ok = true;
+        if (pair) {
 #pragma unroll
-        for (int k = 0; k < NG; k++) {
-            if (c0 < c1) { const fz_u64 x = fz_get(planes + (size_t)k * FZ_MAXB + c0); ok = ok && (uint32_t)(x >> 32) == tag; w0[k] = (uint32_t)x; }
-            if (c0 + 1 < c1) { const fz_u64 x = fz_get(planes + (size_t)k * FZ_MAXB + c0 + 1); ok = ok && (uint32_t)(x >> 32) == tag; w1[k] = (uint32_t)x; }
+            for (int k = 0; k < NG; k++) {
+                const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(rs, (k * FZ_MAXB + c0) * 8, 0, 16);        // aux 16 = sc1
+                ok = ok && x.y == tag && x.w == tag; w0[k] = x.x; w1[k] = x.z;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                if (c0 < c1) { const fz_u64 x = fz_get(planes + (size_t)k * FZ_MAXB + c0); ok = ok && (uint32_t)(x >> 32) == tag; w0[k] = (uint32_t)x; }
+                if (c0 + 1 < c1) { const fz_u64 x = fz_get(planes + (size_t)k * FZ_MAXB + c0 + 1); ok = ok && (uint32_t)(x >> 32) == tag; w1[k] = (uint32_t)x; }
+            }
         }
         if (__all(ok)) return true;
         if ((spins & 15u) == 15u && clk.expired()) { *bail = 1; return false; }
@@ -222,29 +267,58 @@ __device__ __forceinline__ uint64_t fz_resolve_duty(SegSmem& sm, ResolveSmem& rs
     uint32_t w0[FZ_KREC], w1[FZ_KREC];
     bool ok = fz_gather<FZ_KREC>(planes, c0, c1, g.tag, clk, &fs.bail, w0, w1);
     bool unsup = false;
+    BlockRec q0, q1;
+    q0.prefix = rec_identity(0); q0.tail_from = NT; q0.nside = 0; q1 = q0;
     if (ok) {
+        // (the records stay in registers; only side entries -- the last block's, rarely another -- go through the private list)
         if (c0 < c1) {
-            bool u; const BlockRec r = fz_decode(w0, u); unsup = unsup || u;
-            store_brec(g.ws->brec_priv, c0, r);
-            if (!u && r.nside > 0) ok = ok && fz_fetch_sides(sides, g.ws->side_priv, c0, r.nside, g.tag, clk);
+            bool u; q0 = fz_decode(w0, u); unsup = unsup || u;
+            if (!u && q0.nside > 0) ok = ok && fz_fetch_sides(sides, g.ws->side_priv[MODE], c0, q0.nside, g.tag, clk);
         }
         if (c0 + 1 < c1) {
-            bool u; const BlockRec r = fz_decode(w1, u); unsup = unsup || u;
-            store_brec(g.ws->brec_priv, c0 + 1, r);
-            if (!u && r.nside > 0) ok = ok && fz_fetch_sides(sides, g.ws->side_priv, c0 + 1, r.nside, g.tag, clk);
+            bool u; q1 = fz_decode(w1, u); unsup = unsup || u;
+            if (!u && q1.nside > 0) ok = ok && fz_fetch_sides(sides, g.ws->side_priv[MODE], c0 + 1, q1.nside, g.tag, clk);
         }
     }
-    if (!ok) fs.bail = 1;
-    if (unsup) fs.bail = 2;
+    // (a wave that saw an unsupported record may have made the other waves leave their gather early: the larger code wins)
+    if (unsup) atomicMax(&fs.bail, 2); else if (!ok) atomicMax(&fs.bail, 1);
     __syncthreads();                      // (also: this workgroup's plain stores above are visible to its own loads below)
+#ifdef BSSM_DEV_STAMPS
+    if (t == 0) { g.ws->stamps[1][MODE == MODE_W ? 8 : 13] = clock64(); g.ws->pubt[3][8 + (MODE == MODE_W ? 1 : 2)] = (long long)wall_clock64(); }
+#endif
     if (fs.bail) { bail = true; return 0ull; }
     long long lit = 0;
     // the terms of OTHER blocks are not in HBM in a fused run: any literal re-run (lit > 0) voids the result
-    const uint64_t fin = resolve_in_block<MODE, NT, EMIT>(sm, rs, g.ws->brec_priv, g.ws->side_priv, B, B, g.xin, g.N, 1.0, st, true, cin_lds, &lit);
+    // (cumsum pass: nobody needs the state BEHIND the last block -- its record, the one with the lanes next to cum == 1, stays out of the
+    //  walk; the state in front of it is the walk's result)
+    const int upto = (MODE == MODE_P) ? B - 1 : B;
+    const uint64_t fin = resolve_in_block<MODE, NT, EMIT>(sm, rs, g.ws->brec_priv[MODE], g.ws->side_priv[MODE], B, upto, g.xin, g.N, 1.0, st, true, cin_lds, &lit, &q0, &q1);
+    if (EMIT && t == 0) cin_lds[B - 1] = fin;
     if (lit) fs.bail = 2;
     __syncthreads();
+#ifdef BSSM_DEV_STAMPS
+    if (t == 0) g.ws->stamps[1][MODE == MODE_W ? 9 : 14] = clock64();
+#endif
     if (fs.bail) { bail = true; return 0ull; }
     return fin;
+}
+
+__host__ __device__ __forceinline__ int fz_resolver_block(int B) { return (5 * B) / 16; }
+
+// The normals of transition call `call` for this lane's EL slots, to HBM (the next launch reads them as it reads injected draws).
+__device__ __forceinline__ void fz_draw_next(const FusedArgs& g, long long j0, long long N)
+{
+    if (!g.znext) return;
+#pragma unroll
+    for (int i = 0; i < EL / 2; i++) {
+        const long long j = j0 + 2 * i;
+        if (j < N) {
+            double z0, z1;
+            normal_pair(g.ns.key, g.ns.purpose, g.znext_call, 0, (uint32_t)(j >> 1), z0, z1);
+            if (j + 1 < N) { double2 q; q.x = z0; q.y = z1; *reinterpret_cast<double2*>(g.znext + j) = q; }
+            else g.znext[j] = z0;
+        }
+    }
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------
@@ -260,7 +334,20 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
     double* lx = dyn + EB / 2;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int bidx = (int)blockIdx.x, B = g.nblk;
-    const bool resolver = (bidx == B / 2);
+    // the resolver: the worker of a block that (a) is dispatched in the first round of workgroups -- the older of the two
+    // workgroups of its CU wins the VALU arbitration -- and (b) does not sit where the cumulative weight crosses a power of two
+    // (blocks B/2, B/4, ...: their records take the longer path): block 5B/16, at cum ~ 0.31
+    const bool resolver = (bidx == fz_resolver_block(B));
+    if (resolver) __builtin_amdgcn_s_setprio(3);
+    const bool fz_stamper = (t == 0) && (resolver || bidx == ((B > 100) ? 100 : 0)); const int fz_row = resolver ? 1 : 0; (void)fz_stamper; (void)fz_row;
+    FZ_STAMP(0);
+#ifdef BSSM_DEV_STAMPS
+#define FZ_PUBT(k) do { if (t == 0) g.ws->pubt[k][bidx] = (long long)wall_clock64(); } while (0)
+#define FZ_GDONE(k) do { if (t == 0) g.ws->pubt[3][8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define FZ_PUBT(k) do { } while (0)
+#define FZ_GDONE(k) do { } while (0)
+#endif
     const long long b0 = (long long)bidx * EB, j0 = b0 + (long long)t * EL;
     const long long N = g.N;
     FzClock clk; clk.t0 = (long long)wall_clock64();
@@ -285,7 +372,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         const long long j = j0 + 2 * i;
         if (g.trans && j < N) {
             double z0, z1;
-            if (g.ns.arr) { z0 = g.ns.arr[j]; z1 = (j + 1 < N) ? g.ns.arr[j + 1] : 0.0; }
+            if (g.ns.arr) { if (j + 1 < N) { const double2 q = *reinterpret_cast<const double2*>(g.ns.arr + j); z0 = q.x; z1 = q.y; } else { z0 = g.ns.arr[j]; z1 = 0.0; } }
             else normal_pair(g.ns.key, g.ns.purpose, g.ns.call, 0, (uint32_t)(j >> 1), z0, z1);
             x8[2 * i] = Model<MODEL>::transition(x8[2 * i], z0, g.par);
             x8[2 * i + 1] = Model<MODEL>::transition(x8[2 * i + 1], z1, g.par);
@@ -293,6 +380,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         l8[2 * i] = (j < N) ? r_dnorm_log(g.y, x8[2 * i], g.par.sy, g.par.log_sy) : -INFINITY;
         l8[2 * i + 1] = (j + 1 < N) ? r_dnorm_log(g.y, x8[2 * i + 1], g.par.sy, g.par.log_sy) : -INFINITY;
     }
+    FZ_STAMP(1);
     // block (max, sum exp, sum exp^2) in k_step's association order: a k_step thread holds one PAIR, 64 of them make a wave
     // (= one row of 16 lanes here), the 16 wave totals are added in order
     double bm;
@@ -337,6 +425,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         const uint64_t bits = d2b(t < 2 ? bm : (t < 4 ? bsum : bsq));
         fz_put(&g.ws->e1[t][bidx], g.tag, (t & 1) ? (uint32_t)(bits >> 32) : (uint32_t)bits);
     }
+    FZ_STAMP(2); FZ_PUBT(0);
     // ---- resolver duty 1: log-sum-exp combine, log-likelihood, ESS, resample decision (:204-218), block prefixes ----
     if (resolver) {
         const int L = (B + NT - 1) / NT;
@@ -345,6 +434,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         const bool ok = fz_gather<6>(&g.ws->e1[0][0], c0, c1, g.tag, clk, &fs.bail, w0, w1);
         if (!ok) fs.bail = 1;
         __syncthreads();
+        FZ_STAMP(3); FZ_GDONE(0);
         uint32_t status = 0;
         double M = 0.0, S = 0.0, sq = 0.0;
         double esv[2] = {0.0, 0.0}, pre = 0.0;
@@ -401,31 +491,33 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int i = c0 + k;
-                if (k < L && i < c1) {
-                    fz_u64* slot = &g.ws->r1[i][0];
-                    fz_put64(slot + 0, g.tag, d2b(M)); fz_put64(slot + 2, g.tag, d2b(S)); fz_put64(slot + 4, g.tag, d2b(sq));
-                    fz_put64(slot + 6, g.tag, d2b(pp / S));
-                    fz_put(slot + 8, g.tag, status);
-                }
+                if (k < L && i < c1) fz_put64x(&g.ws->a1[0][i], FZ_MAXB, g.tag, d2b(pp / S));
                 pp += esv[k];
+            }
+            if (t < FZ_NREP) {
+                fz_u64* rep = &g.ws->c1[t][0];
+                fz_put64(rep + 0, g.tag, d2b(M)); fz_put64(rep + 2, g.tag, d2b(S)); fz_put64(rep + 4, g.tag, d2b(sq)); fz_put(rep + 6, g.tag, status);
             }
         }
     }
+    if (resolver) FZ_STAMP(4);
     // ---- every worker: its slot of duty 1 ----
     double M, S, a_in;
     uint32_t status;
     {
         if (wave == 0) {
             uint32_t v = 0;
-            const bool ok = fz_wait_slot<9>(&g.ws->r1[bidx][0], g.tag, clk, v);
+            const fz_u64* src = (lane < 7) ? &g.ws->c1[bidx % FZ_NREP][lane] : &g.ws->a1[(lane - 7) & 1][bidx];
+            const bool ok = fz_wait_words<9>(src, g.tag, clk, v);
             if (lane < 9) fs.slot[lane] = v;
             if (!ok && lane == 0) fs.bail = 1;
         }
         __syncthreads();
-        if (fs.bail) { if (t == 0) atomicOr(&st->flags, FLAG_FUSED_TIMEOUT); return; }
-        M = b2d(mk64(fs.slot[0], fs.slot[1])); S = b2d(mk64(fs.slot[2], fs.slot[3])); a_in = b2d(mk64(fs.slot[6], fs.slot[7]));
-        status = fs.slot[8];
+        if (fs.bail) { if (t == 0 && fs.bail == 1) atomicOr(&st->flags, FLAG_FUSED_TIMEOUT); return; }
+        M = b2d(mk64(fs.slot[0], fs.slot[1])); S = b2d(mk64(fs.slot[2], fs.slot[3])); a_in = b2d(mk64(fs.slot[7], fs.slot[8]));
+        status = fs.slot[6];
     }
+    FZ_STAMP(5);
     if (status & (FZ_ST_DEAD | FZ_ST_BAIL)) return;
     const bool doit = status & FZ_ST_DOIT;
     // ---- phase B: w = exp(lw - max) / sum (:205-207) ----
@@ -457,9 +549,11 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         }
         acc0 = block_sum(acc0, sm.sh4);
         if (t == 0) g.a.se_part[bidx] = acc0;
+        fz_draw_next(g, j0, N);
         return;
     }
     if (status & FZ_ST_STOP) return;
+    FZ_STAMP(6);
     // ---- W pass: the block's record of the exact sequential sum(w) (src/resampling.cpp:20,47) ----
     FusedRecSink sink; sink.bidx = bidx; sink.tag = g.tag; sink.terms = lx; sink.v = v; sink.st = st;
     {
@@ -469,6 +563,8 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         sink.rec_planes = &g.ws->e2[0][0]; sink.side_base = &g.ws->side_w[0][0][0];
         block_record_tail<MODE_W, 11>(sm, tin, bsw, v, a_in, g.lim, st, 0, false, sink);
     }
+    FZ_STAMP(7); FZ_PUBT(1);
+    if (!resolver) fz_draw_next(g, j0, N);          // (the resolver draws behind its duty, below)
     ResolveSmem& rs = *reinterpret_cast<ResolveSmem*>(dyn);
     uint64_t* cin_lds = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(dyn) + ((sizeof(ResolveSmem) + 15) / 16) * 16);
     if (resolver) {
@@ -487,22 +583,25 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
             }
             if (tot == 0.0 || !isfinite(tot)) stw = FZ_ST_STOP;
         }
-        for (int b = t; b < B; b += NT) { fz_put64(&g.ws->r2[b][0], g.tag, fin); fz_put(&g.ws->r2[b][2], g.tag, stw); }
+        if (t < FZ_NREP) { fz_put64(&g.ws->c2[t][0], g.tag, fin); fz_put(&g.ws->c2[t][2], g.tag, stw); }
+        fz_draw_next(g, j0, N);
+        FZ_STAMP(10);
     }
     double total;
     {
         __syncthreads();
         if (wave == 0) {
             uint32_t vv = 0;
-            const bool ok = fz_wait_slot<3>(&g.ws->r2[bidx][0], g.tag, clk, vv);
+            const bool ok = fz_wait_slot<3>(&g.ws->c2[bidx % FZ_NREP][0], g.tag, clk, vv);
             if (lane < 3) fs.slot[lane] = vv;
             if (!ok && lane == 0) fs.bail = 1;
         }
         __syncthreads();
-        if (fs.bail) { if (t == 0) atomicOr(&st->flags, FLAG_FUSED_TIMEOUT); return; }
+        if (fs.bail) { if (t == 0 && fs.bail == 1) atomicOr(&st->flags, FLAG_FUSED_TIMEOUT); return; }
         if (fs.slot[2] & (FZ_ST_BAIL | FZ_ST_STOP)) return;
         total = b2d(mk64(fs.slot[0], fs.slot[1]));
     }
+    FZ_STAMP(11);
     // ---- P pass: prob = w / total, the block's record of cumsum(prob) (src/resampling.cpp:24-25,51-52) ----
     const double a_in_p = a_in / total;
 #pragma unroll
@@ -512,6 +611,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
     __syncthreads();
     sink.rec_planes = &g.ws->e3[0][0]; sink.side_base = &g.ws->side_p[0][0][0];
     block_record_tail<MODE_P, 3>(sm, tin, bs, v, a_in_p, g.lim, st, 0, false, sink);
+    FZ_STAMP(12); FZ_PUBT(2);
     uint64_t cinb = 0;
     if (resolver) {
         // ---- duty 3: every block's exact incoming state ----
@@ -520,7 +620,9 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         (void)fz_resolve_duty<MODE_P, true>(sm, rs, fs, g, st, clk, cin_lds, bail);
         uint32_t stp = 0;
         if (bail) { stp = FZ_ST_BAIL; if (t == 0) atomicOr(&st->flags, fs.bail == 1 ? FLAG_FUSED_TIMEOUT : FLAG_FUSED_BAIL); }
-        for (int b = t; b < B; b += NT) { fz_put64(&g.ws->r3[b][0], g.tag, bail ? 0ull : cin_lds[b]); fz_put(&g.ws->r3[b][2], g.tag, stp); }
+        for (int b = t; b < B; b += NT) fz_put64x(&g.ws->a3[0][b], FZ_MAXB, g.tag, bail ? 0ull : cin_lds[b]);
+        if (t < FZ_NREP) fz_put(&g.ws->c3[t][0], g.tag, stp);
+        FZ_STAMP(15);
         if (bail) return;
         cinb = cin_lds[bidx];
         __syncthreads();                  // (the staging area is about to be reused by this workgroup's own expansion)
@@ -528,21 +630,24 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         __syncthreads();
         if (wave == 0) {
             uint32_t vv = 0;
-            const bool ok = fz_wait_slot<3>(&g.ws->r3[bidx][0], g.tag, clk, vv);
+            const fz_u64* src = (lane < 2) ? &g.ws->a3[lane & 1][bidx] : &g.ws->c3[bidx % FZ_NREP][0];
+            const bool ok = fz_wait_words<3>(src, g.tag, clk, vv);
             if (lane < 3) fs.slot[lane] = vv;
             if (!ok && lane == 0) fs.bail = 1;
         }
         __syncthreads();
-        if (fs.bail) { if (t == 0) atomicOr(&st->flags, FLAG_FUSED_TIMEOUT); return; }
+        if (fs.bail) { if (t == 0 && fs.bail == 1) atomicOr(&st->flags, FLAG_FUSED_TIMEOUT); return; }
         if (fs.slot[2] & FZ_ST_BAIL) return;
         cinb = mk64(fs.slot[0], fs.slot[1]);
     }
+    FZ_STAMP(16);
     // ---- phase D: exact cum_sum, output counts, ancestors, particles[indices, ] (src/resampling.cpp:28-37,55-63) ----
     uint64_t ent;
     {
         const bool good = block_resolve<MODE_P>(sm, bs, cinb, g.lim, nullptr, 0, total, b0, ent);
         if (!good) { fz_block_literal(tin, cinb, lx, v, st); ent = tin[t]; }
     }
+    FZ_STAMP(17);
     // the particles in the expansion's lane-interleaved layout (element wave * 64 * EL + 64 k + lane), through LDS
     double xs0[EL], xs1[EL], axs[EL];
     __syncthreads();
@@ -563,6 +668,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
     //  degenerate-weights path, which does not stage)
     __syncthreads();
     apply_tail<KIND, false, CAPX, false>(sm, Tl, Tbegin, bidx, B, g.a, st, g.a.nstage ? lx + EB : nullptr, g.a.nstage, v, ent, xs0, xs1, axs, call, us, Usys, 0, false, lx);
+    FZ_STAMP(18);
 }
 
 constexpr size_t FZ_DYN_LDS = (size_t)EB * sizeof(int) + (size_t)(EB + CAPX) * sizeof(double);

@@ -712,6 +712,9 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int j)
 // its four 16-byte reads (profiles/r02_a_stage_stamps_typical_block.txt: 10 links in 5000 cycles).
 // Returns how many leading links accepted their state (jd); lane j < jd gets (my_s, my_out) = the state before / after its
 // link; s = the state before link jd.
+// (Round 3 tried the opposite split: lane j's constants read into scalar registers one link ahead (13 v_readlane per link) and the link
+//  evaluated on the scalar unit.  The compiler does emit s_cselect / s_lshr_b64 / s_add for it, but the chain of 10 links took 3.9k cycles
+//  against 2.6k here: the readlanes cost more than the VALU -> SGPR round trip they remove.  profiles/r03_c_rejected_variants.txt)
 __device__ __forceinline__ int walk_chain_regs(const WalkFn& w, int nent, uint64_t& s, uint64_t& my_s, uint64_t& my_out)
 {
     const int lane = threadIdx.x & 63;
@@ -1562,7 +1565,9 @@ template <int MODE, int NTX = NT, bool EMIT = false>
 __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& rs, const BlockRec* __restrict__ brec,
                                                      const SideList* __restrict__ side, const int B, const int upto,
                                                      const double* __restrict__ w, long long nw, double total, DevState* st,
-                                                     const bool count_stats, uint64_t* __restrict__ cin_out = nullptr)
+                                                     const bool count_stats, uint64_t* __restrict__ cin_out = nullptr,
+                                                     long long* lit_out = nullptr /* this thread's count of literally re-run terms */,
+                                                     const BlockRec* pre0 = nullptr, const BlockRec* pre1 = nullptr /* the thread's records, already in registers */)
 {
     const int t = threadIdx.x;
     if (upto <= 0) return 0ull;                        // (block-uniform)
@@ -1574,8 +1579,8 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     const int c0 = t * CB, c1 = (c0 + CB < upto) ? c0 + CB : upto;
     BlockRec r0, r1;
     r0.prefix = rec_identity(0); r0.tail_from = NT; r0.nside = 0; r1 = r0;
-    if (c0 < c1) r0 = load_brec(brec, c0);
-    if (c0 + 1 < c1) r1 = load_brec(brec, c0 + 1);
+    if (c0 < c1) r0 = pre0 ? *pre0 : load_brec(brec, c0);
+    if (c0 + 1 < c1) r1 = pre1 ? *pre1 : load_brec(brec, c0 + 1);
     if (t == 0) { rs.sout[0] = 0; rs.fail = 0; }
     // the last block of a full pass nearly always carries one side entry (the lanes next to cum == 1.0 are never PURE):
     // fetch it now, with the records, so that the walk does not wait for a dependent global load later
@@ -1694,6 +1699,11 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     __syncthreads();
     if (rs.fail) {
         // the records did not cover the exact states: one lane walks every block (each step is still exact)
+        if (pre0) {      // (records handed over in registers: the walking lane reads them from `brec`, which the caller owns)
+            if (c0 < c1) store_brec(const_cast<BlockRec*>(brec), c0, r0);
+            if (c0 + 1 < c1) store_brec(const_cast<BlockRec*>(brec), c0 + 1, r1);
+            __syncthreads();
+        }
         if (t == 0) {
             uint64_t sf = 0;
             for (int b = 0; b < upto; b++) { const BlockRec r = load_brec(brec, b); if (EMIT) cin_out[b] = sf; sf = block_out_exact<MODE>(r, side, w, nw, total, b, sf, lit); }
@@ -1703,6 +1713,7 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
         __syncthreads();
     }
     if (lit && count_stats) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
+    if (lit_out) *lit_out = lit;
     BSSM_STAMP(st, dbg, MODE, 7, stamper);
 #ifdef BSSM_DEV_STAMPS
     if ((dbg == 99 || dbg == 98) && stamper) { st->stamps[MODE][8] = E; st->stamps[MODE][9] = upto; }

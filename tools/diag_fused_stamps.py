@@ -1,0 +1,57 @@
+"""Dev tool (needs a DEV=1 build, BAYESSSM_AMD_LIB=...): stage stamps of the fused per-observation kernel, C2 workload."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bayesssm_amd as B
+from bayesssm_amd import _lib
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+rng = np.random.default_rng(1)
+cx = B.Context(0, 1 << 20, 1)
+cx.set_option("debug_stop", 99)
+m = B.models.linear_gaussian()
+x, ys = 0.0, []
+for _ in range(30):
+    x = 0.8 * x + rng.standard_normal(); ys.append(x + rng.standard_normal())
+r = B.bootstrap_filter(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, resample_algorithm="SISR", resample_fn="systematic",
+                       return_particles=False, seed=7, stream=1, ctx=cx, phi=0.8, sigma_x=1.0, sigma_y=1.0)
+print("device us/obs %.2f  stats %s" % (r["_extras"]["device_ms"] * 1e3 / len(ys), cx.fused_stats()))
+out = (C.c_longlong * 48)()
+_lib.check(_lib.load().bssm_ctx_fused_stamps(cx.handle, out))
+s = np.array(list(out)).reshape(2, 24)
+names = ["start", "A: transition+weights", "partials published", "R: gathered partials", "R: duty 1 published", "got slot 1", "B: weights",
+         "W scan + record published", "R: gathered W records", "R: resolved W", "R: total published", "got total", "P scan + record published",
+         "R: gathered P records", "R: resolved P", "R: states published", "got state", "block_resolve", "expansion done"]
+for row, who in ((0, "worker (block 100)"), (1, "resolver (block 5B/16)")):
+    print(who)
+    t0 = s[row][0]
+    prev = t0
+    for k, nm in enumerate(names):
+        if s[row][k]:
+            print("   %-28s +%7d  (at %7d)" % (nm, s[row][k] - prev, s[row][k] - t0))
+            prev = s[row][k]
+print("resolver start - worker start: %d cycles" % (s[1][0] - s[0][0]))
+
+lib = _lib.load()
+lib.bssm_ctx_fused_pubt.argtypes = [C.c_void_p, C.c_void_p]
+pt = (C.c_longlong * 2048)()
+_lib.check(lib.bssm_ctx_fused_pubt(cx.handle, pt))
+p = np.array(list(pt)).reshape(4, 512)
+Bn = (N + 2047) // 2048
+for k, nm in enumerate(["partials", "W records", "P records"]):
+    pub = p[k][:Bn]
+    gd = p[3][8 + k]
+    print("%-10s publish times (10 ns ticks, relative to the earliest): median %d, p90 %d, max %d (block %d); resolver gather done %d after the last publish; resolver's own publish at %d" % (
+        nm, np.median(pub) - pub.min(), np.percentile(pub, 90) - pub.min(), pub.max() - pub.min(), int(pub.argmax()), gd - pub.max(), pub[(5 * Bn) // 16] - pub.min()))
+
+st = (C.c_longlong * 64)()
+_lib.check(lib.bssm_ctx_get_stamps(cx.handle, st))
+r = np.array(list(st)).reshape(4, 16)[1]
+lab = {2: "classify + scan + links", 3: "link set-up", 4: "chain", 5: "general loop", 6: "barrier", 7: "verify (+ emit)"}
+prev = r[0]
+print("resolver duty 3 (P, EMIT) inside resolve_in_block:")
+for k in (2, 3, 4, 5, 6, 7):
+    print("   %-26s +%6d" % (lab[k], r[k] - prev)); prev = r[k]
+print("   links %d" % r[8])
