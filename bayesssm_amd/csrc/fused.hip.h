@@ -607,10 +607,23 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
 #pragma unroll
     for (int k = 0; k < EL; k++) v[k] = v[k] / total;
     BlockScan bs;
+#ifdef BSSM_DEV_STAMPS
+    const bool xstamper = (t == 0 && bidx == B / 4);       // a block with a binade crossing (cum ~ 1/4)
+    const int xdbg = 99;
+    if (xstamper) st->stamps[2][10] = clock64();
+#else
+    const bool xstamper = false; const int xdbg = 0;
+#endif
     block_scan<MODE_P>(sm, v, a_in_p, g.lim, bs);
     __syncthreads();
+#ifdef BSSM_DEV_STAMPS
+    if (xstamper) st->stamps[2][11] = clock64();
+#endif
     sink.rec_planes = &g.ws->e3[0][0]; sink.side_base = &g.ws->side_p[0][0][0];
-    block_record_tail<MODE_P, 3>(sm, tin, bs, v, a_in_p, g.lim, st, 0, false, sink);
+    block_record_tail<MODE_P, 3>(sm, tin, bs, v, a_in_p, g.lim, st, xdbg, xstamper, sink);
+#ifdef BSSM_DEV_STAMPS
+    if (xstamper) { st->stamps[2][9] = clock64(); st->stamps[2][8] = bs.nb; }
+#endif
     FZ_STAMP(12); FZ_PUBT(2);
     uint64_t cinb = 0;
     if (resolver) {

@@ -747,9 +747,9 @@ struct SegSmem {
     double bnd_terms[MAXBND][EL];    // the terms of every boundary lane (so a literal re-run never chases global memory)
     uint64_t seg_start[MAXBND + 1];
     long long red_min[NWV][2], red_max[NWV][2];
-    uint64_t seg1_base;
-    uint64_t segbase[MAXBND + 1]; int smin[MAXBND + 1]; int smax[MAXBND + 1];
-    int nb; int fail; int first_bnd; int big;
+    uint64_t lane_base[NT];          // every lane's hypothesis base (block_scan): a segment's base is its first lane's, read without a barrier round
+    int smin[MAXBND + 1]; int smax[MAXBND + 1];
+    int nb; int fail; int big;
     double sh4[16];
     double bcast;
 };
@@ -942,6 +942,7 @@ __device__ __forceinline__ void block_scan(SegSmem& sm, const double (&v)[EL], d
     bs.pleaf.d0 = (int64_t)(bs.leaf.o[0] - bs.leaf.base);
     bs.pleaf.d1 = (int64_t)(bs.leaf.o[1] - (bs.leaf.base + 1));
     bs.exc = seg_excl_scan<NT / 64>(sm, bs.pleaf, bs.isb, bs.seg, bs.nb, bs.last_seg);
+    sm.lane_base[threadIdx.x] = bs.leaf.base;
     // publish the boundaries in lane order
     if (bs.isb && bs.seg < MAXBND) {
         Rec& d = sm.bnd_rec[bs.seg];
@@ -1066,13 +1067,29 @@ __device__ __forceinline__ void block_literal_terms(uint64_t* tin /* LDS [NT] */
     __syncthreads();
 }
 
-// block-wide min and max of two int64 pairs (segments 0 and 1), lanes opt in per segment
+// block-wide min and max of two pairs (segments 0 and 1), lanes opt in per segment.  The values are offsets in ulps; every use clamps what
+// it derives from them to +-2^30 (pure_to_rec, the side entries), so the reductions run on values saturated to 32 bits (half the DPP
+// moves of the 64-bit scans; results identical after the clamp).  The caller has passed a barrier since the last read of sm.red_*.
+__device__ __forceinline__ int wave_min_i32(int x)
+{
+#define STEP(C, R) { const int y = dpp_i32<C, R>(x, x); x = y < x ? y : x; }
+    BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
+    return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int x)
+{
+#define STEP(C, R) { const int y = dpp_i32<C, R>(x, x); x = y > x ? y : x; }
+    BSSM_WAVE_SCAN_STEPS(STEP)
+#undef STEP
+    return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ int sat_i32(long long x) { return x > 0x7fffffffll ? 0x7fffffff : (x < -0x7fffffffll ? -0x7fffffff : (int)x); }
 __device__ __forceinline__ void block_minmax2(SegSmem& sm, long long mn[2], long long mx[2])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long a0 = lane63_i64(wave_incl_min_i64(mn[0])), a1 = lane63_i64(wave_incl_min_i64(mn[1]));
-    const long long b0 = lane63_i64(wave_incl_max_i64(mx[0])), b1 = lane63_i64(wave_incl_max_i64(mx[1]));
-    __syncthreads();
+    const int a0 = wave_min_i32(sat_i32(mn[0])), a1 = wave_min_i32(sat_i32(mn[1]));
+    const int b0 = wave_max_i32(sat_i32(mx[0])), b1 = wave_max_i32(sat_i32(mx[1]));
     if (lane == 0) { sm.red_min[wave][0] = a0; sm.red_min[wave][1] = a1; sm.red_max[wave][0] = b0; sm.red_max[wave][1] = b1; }
     __syncthreads();
 #pragma unroll
@@ -1113,6 +1130,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
 {
     const int t = threadIdx.x;
     (void)dbg; (void)stamper;
+    BSSM_STAMP(st, dbg, 2, 12, stamper);
     const uint64_t hb0 = d2b(a_in) & ~3ull;
     if (a_in == 0.0) {
         // exact incoming state (+0): resolve now and publish the exact outgoing state
@@ -1129,19 +1147,15 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
         return;
     }
     // validity windows of segment 0 (lanes before the first boundary) and of the last segment when nb == 1
+    // (round 3: the first boundary lane and the base of the segment behind it are read from what block_scan published -- the three
+    //  barrier rounds that used to find them made the blocks with a binade crossing publish ~1 us after the others, and a grid-level
+    //  resolve waits for the last record)
     int fb = NT;
-    if (bs.nb > 0) {                       // (block-uniform; the typical block has no boundary lane and skips three barriers)
-        if (t == 0) sm.first_bnd = NT;
-        __syncthreads();
-        if (bs.isb && bs.seg == 0) sm.first_bnd = t;
-        __syncthreads();
-        fb = sm.first_bnd;
-        if (t == fb + 1) sm.seg1_base = bs.leaf.base;
-        __syncthreads();
-    }
+    uint64_t seg1_base = 0;
+    if (bs.nb > 0) { fb = sm.bnd_lane[0]; if (fb + 1 < NT) seg1_base = sm.lane_base[fb + 1]; }
     long long mn[2] = {(1ll << 40), (1ll << 40)}, mx[2] = {-(1ll << 40), -(1ll << 40)};
     if (!bs.isb && bs.seg <= 1) {
-        const uint64_t sb = (bs.seg == 0) ? hb0 : (sm.seg1_base & ~3ull);
+        const uint64_t sb = (bs.seg == 0) ? hb0 : (seg1_base & ~3ull);
         const long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
         const long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
         const long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
@@ -1157,37 +1171,85 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
         }
         return;
     }
-    bool done1 = false;
-    if (t == fb) {
-        // bs.exc of the first boundary lane = composite of segment 0
-        Rec pre = (fb == 0) ? rec_identity(hb0) : pure_to_rec(bs.exc, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
-        BlockRec br;
-        if (bs.nb == 1 && bs.leaf.kind == REC_X1) {
-            Rec r = rec_compose(pre, bs.leaf);
-            if (fb < NT - 1) {
-                const Rec post = pure_to_rec(bs.last_seg, sm.seg1_base, -(long long)lim - mn[1] + 4, (long long)lim - mx[1] - 4);
-                r = rec_compose(r, post);
+    BSSM_STAMP(st, dbg, 2, 13, stamper);
+    // One boundary, a binade crossing (REC_X1): the block's record is  pre . crossing . post  composed into ONE X1 record.  The four
+    // hypotheses s = 0..3 are independent, so lanes 0..3 compose one each (rec_compose's arithmetic, lane-parallel: the serial form
+    // ran ~600 instructions on one lane while the other 255 waited -- and with them every block of the grid, see above).
+    if (t < 4) {
+        const Pure ex0 = sm.bnd_excl[0];                     // composite of segment 0 (the first boundary lane's exclusive scan)
+        const Rec leaf = sm.bnd_rec[0];
+        const long long C30 = (1ll << 30);
+        auto clamp30 = [&](long long x) { return x < -C30 ? -C30 : (x > C30 ? C30 : x); };
+        // (lanes 0..3 are one DPP quad: quad_perm [1,0,3,2] = 0xB1 and [2,3,0,1] = 0x4E exchange with lane ^ 1 and lane ^ 2)
+        auto min4 = [&](long long x) { long long y = dpp_i64<0xB1, 0xf>(x, x); x = y < x ? y : x; y = dpp_i64<0x4E, 0xf>(x, x); return y < x ? y : x; };
+        auto max4 = [&](long long x) { long long y = dpp_i64<0xB1, 0xf>(x, x); x = y > x ? y : x; y = dpp_i64<0x4E, 0xf>(x, x); return y > x ? y : x; };
+        // pre = rec_identity(hb0) or pure_to_rec(ex0, hb0, ...): this lane's hypothesis
+        const uint64_t pbase = hb0 & ~3ull;
+        const long long plo = (fb == 0) ? -C30 : clamp30(-(long long)lim - mn[0] + 4), phi = (fb == 0) ? C30 : clamp30((long long)lim - mx[0] - 4);
+        const uint64_t po = pbase + (uint64_t)t + ((fb == 0) ? 0ull : (uint64_t)((t & 1) ? ex0.d1 : ex0.d0));
+        bool done1 = false;
+        uint64_t fo = 0; long long flo = 0, fhi = 0;
+        if (bs.nb == 1 && leaf.kind == REC_X1) {
+            // r = rec_compose(pre, leaf)
+            bool ok = true;
+            {
+                const long long m = (long long)(po - leaf.base);
+                long long lo = (long long)leaf.lo - min4(m) + 8, hi = (long long)leaf.hi - max4(m) - 8;
+                lo = lo < plo ? plo : lo; hi = hi > phi ? phi : hi;
+                ok = !(lo > 0 || hi < 3);
+                const int64_t diff = (int64_t)(po - leaf.base);
+                ok = ok && !(diff < (int64_t)leaf.lo || diff > (int64_t)leaf.hi);
+                const int64_t sx = diff & 3, q4 = diff - sx;
+                const uint64_t os = (sx == 0) ? leaf.o[0] : (sx == 1) ? leaf.o[1] : (sx == 2) ? leaf.o[2] : leaf.o[3];
+                fo = os + (uint64_t)(q4 >> 1); flo = (long long)(int32_t)lo; fhi = (long long)(int32_t)hi;
             }
-            if (r.kind != REC_HARD) { br.prefix = r; br.tail_from = NT; br.nside = 0; sink.rec(br); done1 = true; }
+            ok = __all(ok);                                       // (lanes 0..3 are the active ones here)
+            if (ok && fb < NT - 1) {
+                // r = rec_compose(r, post),  post = pure_to_rec(last_seg, seg1_base, ...)
+                const uint64_t gbase = seg1_base & ~3ull;
+                const long long glo = clamp30(-(long long)lim - mn[1] + 4), ghi = clamp30((long long)lim - mx[1] - 4);
+                const long long m = (long long)(fo - gbase);
+                long long lo = (glo - min4(m) + 8) * 2, hi = (ghi - max4(m) - 8) * 2;
+                lo = lo < flo ? flo : lo; hi = hi > fhi ? fhi : hi;
+                bool ok2 = !(lo > 0 || hi < 3);
+                const int64_t diff = (int64_t)(fo - gbase);
+                ok2 = ok2 && !(diff < (int64_t)glo || diff > (int64_t)ghi);
+                const int64_t sx = diff & 3, q4 = diff - sx;
+                // post.o[sx] = gbase + sx + (sx odd ? d1 : d0)
+                fo = gbase + (uint64_t)sx + (uint64_t)((sx & 1) ? bs.last_seg.d1 : bs.last_seg.d0) + (uint64_t)q4;
+                flo = (long long)(int32_t)lo; fhi = (long long)(int32_t)hi;
+                ok = __all(ok2);
+            }
+            done1 = ok;
         }
-        if (!done1) {
-            br.prefix = pre;
-            if (bs.nb <= MAXBND) { br.tail_from = NT; br.nside = bs.nb; }     // side list below
-            else { br.tail_from = fb; br.nside = 0; }                          // too many: literal tail
+        // lane 0 collects the four outgoing states (of the composite, or of pre) and publishes the record
+        const uint64_t src = done1 ? fo : po;
+        const uint64_t o1 = (uint64_t)dpp_i64<0x55, 0xf>((long long)src, (long long)src), o2 = (uint64_t)dpp_i64<0xAA, 0xf>((long long)src, (long long)src),
+                       o3 = (uint64_t)dpp_i64<0xFF, 0xf>((long long)src, (long long)src);      // quad_perm broadcasts of lanes 1, 2, 3
+        if (t == 0) {
+            BlockRec br;
+            br.prefix.base = pbase; br.prefix.o[0] = src; br.prefix.o[1] = o1; br.prefix.o[2] = o2; br.prefix.o[3] = o3; br.prefix.pad = 0;
+            if (done1) { br.prefix.kind = REC_X1; br.prefix.lo = (int32_t)flo; br.prefix.hi = (int32_t)fhi; br.tail_from = NT; br.nside = 0; }
+            else {
+                br.prefix.kind = REC_PURE; br.prefix.lo = (int32_t)plo; br.prefix.hi = (int32_t)phi;
+                if (bs.nb <= MAXBND) { br.tail_from = NT; br.nside = bs.nb; }     // side list below
+                else { br.tail_from = fb; br.nside = 0; }                          // too many: literal tail
+                atomicAdd((unsigned long long*)&st->stat_hard_blocks, 1ull);
+            }
             sink.rec(br);
-            atomicAdd((unsigned long long*)&st->stat_hard_blocks, 1ull);
+            sm.fail = done1 ? 1 : 0;      // reuse as "record complete" flag for the block
         }
-        sm.fail = done1 ? 1 : 0;      // reuse as "record complete" flag for the block
     }
+    BSSM_STAMP(st, dbg, 2, 14, stamper);
     __syncthreads();
+    BSSM_STAMP(st, dbg, 2, 15, stamper);
     if (sm.fail || bs.nb > MAXBND) return;
     // ---- side list: every boundary leaf + the PURE segment after it, with that segment's window ----
     for (int k = t; k <= MAXBND; k += NT) { sm.smin[k] = 0x7fffffff; sm.smax[k] = -0x7fffffff; }
-    // the first lane of a segment (the lane after boundary seg-1) publishes the segment's hypothesis base
-    if (!bs.isb && bs.seg >= 1 && t == sm.bnd_lane[bs.seg - 1] + 1) sm.segbase[bs.seg] = bs.leaf.base;
+    // (a segment's hypothesis base is that of its first lane, the lane behind boundary seg - 1: sm.lane_base)
     __syncthreads();
     if (!bs.isb && bs.seg >= 1) {
-        const uint64_t sb = sm.segbase[bs.seg] & ~3ull;
+        const uint64_t sb = sm.lane_base[sm.bnd_lane[bs.seg - 1] + 1] & ~3ull;
         long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
         long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
         long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
@@ -1204,7 +1266,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
         const Pure post = (k + 1 < bs.nb) ? sm.bnd_excl[k + 1] : bs.last_seg;
         e.d0 = post.d0; e.d1 = post.d1;
         const bool has_post = (sm.smin[k + 1] != 0x7fffffff);
-        e.post_base = has_post ? (sm.segbase[k + 1] & ~3ull) : 0ull;
+        e.post_base = has_post ? (sm.lane_base[t + 1] & ~3ull) : 0ull;       // (has_post: lane t + 1 is the segment's first lane)
         const long long lo = has_post ? (-(long long)lim - (long long)sm.smin[k + 1] + 4) : -(1ll << 30);
         const long long hi = has_post ? ((long long)lim - (long long)sm.smax[k + 1] - 4) : (1ll << 30);
         e.lo = (int32_t)(lo < -(1ll << 30) ? -(1ll << 30) : (lo > (1ll << 30) ? (1ll << 30) : lo));

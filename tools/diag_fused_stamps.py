@@ -45,6 +45,8 @@ for k, nm in enumerate(["partials", "W records", "P records"]):
     gd = p[3][8 + k]
     print("%-10s publish times (10 ns ticks, relative to the earliest): median %d, p90 %d, max %d (block %d); resolver gather done %d after the last publish; resolver's own publish at %d" % (
         nm, np.median(pub) - pub.min(), np.percentile(pub, 90) - pub.min(), pub.max() - pub.min(), int(pub.argmax()), gd - pub.max(), pub[(5 * Bn) // 16] - pub.min()))
+    late = np.argsort(pub)[::-1][:10]
+    print("           latest blocks: " + ", ".join("%d (+%d)" % (int(b), pub[b] - pub.min()) for b in late))
 
 st = (C.c_longlong * 64)()
 _lib.check(lib.bssm_ctx_get_stamps(cx.handle, st))
@@ -55,3 +57,7 @@ print("resolver duty 3 (P, EMIT) inside resolve_in_block:")
 for k in (2, 3, 4, 5, 6, 7):
     print("   %-26s +%6d" % (lab[k], r[k] - prev)); prev = r[k]
 print("   links %d" % r[8])
+
+r2 = np.array(list(st)).reshape(4, 16)[2]
+print("crossing block (B/4), P pass: boundaries %d; block_scan %d, tail entry %d, minmax2 %d, compose %d, barrier %d, to the end %d" % (
+    r2[8], r2[11] - r2[10], r2[12] - r2[11], r2[3] - r2[12], r2[14] - r2[13], r2[15] - r2[14], r2[9] - r2[15]))

@@ -50,7 +50,7 @@ while time.time() - t0 < budget:
         if out["status"][k] != 0:
             bad += 1; print("STATUS MISMATCH (batch only)", model, alg, N, T, ra, rf, out["status"][k], flush=True); continue
         same = (out["loglike"][k] == ref[k]["loglike"] or (np.isnan(out["loglike"][k]) and np.isnan(ref[k]["loglike"]))) and \
-            np.array_equal(out["ess"][k], ref[k]["ess"]) and np.array_equal(out["state_est"][k], ref[k]["state_est"]) and \
+            np.array_equal(out["ess"][k], ref[k]["ess"]) and np.array_equal(out["state_est"][k], ref[k]["state_est"], equal_nan=True) and \
             np.array_equal(out["loglike_history"][k], ref[k]["loglike_history"])
         if not same:
             bad += 1; print("MISMATCH", model, alg, N, T, ra, rf, ot is not None, flush=True)

@@ -41,7 +41,7 @@ while time.time() - t0 < budget:
             rel = abs(r["loglike"] - ref["loglike"]) / max(abs(ref["loglike"]), 1e-300); worst = max(worst, rel); ok &= rel <= 1e-6 or abs(r["loglike"] - ref["loglike"]) < 1e-9
         else:
             ok &= r["loglike"] == ref["loglike"]
-        ok &= np.allclose(r["ess"], ref["ess"], rtol=1e-6) and np.allclose(r["state_est"], ref["state_est"], rtol=1e-6, atol=1e-8)
+        ok &= np.allclose(r["ess"], ref["ess"], rtol=1e-6) and np.allclose(r["state_est"], ref["state_est"], rtol=1e-6, atol=1e-8, equal_nan=True)
         ok &= bool((r["_extras"]["resampled"] == ref["resampled"]).all())
         if not ok:
             bad += 1; print("MISMATCH", tag, r["loglike"], ref["loglike"], flush=True)
@@ -75,7 +75,7 @@ while time.time() - t0 < budget:
         rel = abs(r["loglike"] - ref["loglike"]) / max(abs(ref["loglike"]), 1e-300); worst = max(worst, rel); ok &= rel <= 1e-6 or abs(r["loglike"] - ref["loglike"]) < 1e-9
     else:
         ok &= r["loglike"] == ref["loglike"]
-    ok &= np.allclose(r["ess"], ref["ess"], rtol=1e-6) and np.allclose(r["state_est"], ref["state_est"], rtol=1e-6, atol=1e-8)
+    ok &= np.allclose(r["ess"], ref["ess"], rtol=1e-6) and np.allclose(r["state_est"], ref["state_est"], rtol=1e-6, atol=1e-8, equal_nan=True)
     ok &= bool((r["_extras"]["resampled"] == ref["resampled"]).all())
     if not ok:
         bad += 1; print("MISMATCH", model, alg, N, T, ra, rf, ot, seed, stream, r["loglike"], ref["loglike"], flush=True)
