@@ -1004,7 +1004,9 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
     if (cfg->return_particles || cfg->return_ancestors) ARGFAIL("bssm_pf_run_sharded: histories are not available");
     if (N <= 0 || N % ((long long)W * EB) != 0) ARGFAIL("bssm_pf_run_sharded: num_particles must be a multiple of world x 2048");
     const int B = (int)(N / EB), nloc = B / W, boff = sh->rank * nloc;
-    if (B > 2 * NT) { g_err = "bssm_pf_run_sharded: at most 2^20 particles (every rank resolves the block records itself)"; return BSSM_ERR_CAPACITY; }
+    if (B > MAXB) { g_err = "bssm_pf_run_sharded: at most 2^22 particles in all (the block-record workspace of this build; every rank resolves the records of all blocks itself)"; return BSSM_ERR_CAPACITY; }
+    // up to 2 NT blocks every workgroup resolves the records itself (as on one GPU); above, one 1024-thread workgroup per rank does (k_resolve_all)
+    const bool inres = B <= 2 * NT;
     if (N > c->cap) { g_err = "bssm_pf_run_sharded: num_particles exceeds context capacity"; return BSSM_ERR_CAPACITY; }
     if (T < 0 || (T > 0 && !cfg->y) || !cfg->theta || cfg->n_theta < 3) ARGFAIL("bssm_pf_run_sharded: bad filter configuration");
     if (!res->state_est || !res->ess || !res->loglike || (T > 0 && !res->loglike_history)) ARGFAIL("bssm_pf_run_sharded: result buffers missing");
@@ -1039,7 +1041,26 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
     auto sync = [&]() -> int { HIPCHK(hipStreamSynchronize(c->stream)); return BSSM_OK; };
 #define SHCHK(expr) do { if ((expr) != 0) { g_err = "bssm_pf_run_sharded: a collective callback failed"; return BSSM_ERR_ARG; } } while (0)
     // all_gather of one per-block device array slice [boff, boff + nloc) x item bytes, written back to the full device array
+    const bool devbuf = sh->device_buffers != 0;
+    // device-buffer collectives of small HOST data (the ranks' output ranges + status): staged through two device words
+    void* d_small = nullptr;
+    if (devbuf) { if ((rc = pool_get(c, "sh_small", (size_t)64 * (W + 1), &d_small))) return rc; }
+    auto gather_host = [&](const void* send, void* recv, size_t bytes) -> int {
+        if (!devbuf) { SHCHK(sh->all_gather(sh->user, send, recv, (long long)bytes)); return BSSM_OK; }
+        char* ds = (char*)d_small; char* dr = ds + 64;
+        HIPCHK(hipMemcpyAsync(ds, send, bytes, hipMemcpyHostToDevice, c->stream));
+        if (int r2 = sync()) return r2;
+        SHCHK(sh->all_gather(sh->user, ds, dr, (long long)bytes));
+        if (int r2 = sync()) return r2;
+        HIPCHK(hipMemcpy(recv, dr, bytes * W, hipMemcpyDeviceToHost));
+        return BSSM_OK;
+    };
     auto gather_blocks = [&](void* d_arr, size_t item) -> int {
+        if (devbuf) {      // in place on the device array: rank r's slice sits at r x nloc x item already
+            if (int r2 = sync()) return r2;
+            SHCHK(sh->all_gather(sh->user, (char*)d_arr + (size_t)boff * item, d_arr, (long long)((size_t)nloc * item)));
+            return sync();
+        }
         HIPCHK(hipMemcpyAsync(hsend.data(), (char*)d_arr + (size_t)boff * item, (size_t)nloc * item, hipMemcpyDeviceToHost, c->stream));
         if (int r2 = sync()) return r2;
         SHCHK(sh->all_gather(sh->user, hsend.data(), hrecv.data(), (long long)((size_t)nloc * item)));
@@ -1090,7 +1111,12 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
             // (2) the records of sum(w), (3) the records of cumsum(w / total): every rank resolves them itself
             for (int q = 0; q < 4; q++) if ((rc = gather_blocks((char*)c->brec + (size_t)q * BREC_STRIDE * 16, 16))) return rc;      // (the records live in four planes)
             if ((rc = gather_blocks(c->side, sizeof(SideList)))) return rc;
-            LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), nloc, NT, 0, c->w, N, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p, boff, B);
+            if (inres) LAUNCH(c, "k_local<P>(+resolve<W>)", (k_local<MODE_P, false, true>), nloc, NT, 0, c->w, N, c->ain_w, lim, c->brec_p, c->side_p, c->st, f, c->brec, c->side, c->ain_p, boff, B);
+            else {
+                // (ain_w holds the approximate prefix of EVERY block on every rank: the publishing block of k_weights derives them all from the gathered partials)
+                LAUNCH(c, "k_resolve_all<W>", k_resolve_all<MODE_W>, 1, NTR, 0, c->w, N, B, c->brec, c->side, c->cin, c->ain_w, c->ain_p, c->st);
+                LAUNCH(c, "k_local<P>", (k_local<MODE_P, false>), nloc, NT, 0, c->w, N, c->ain_p, lim, c->brec_p, c->side_p, c->st, f, nullptr, nullptr, nullptr, boff, B);
+            }
             for (int q = 0; q < 4; q++) if ((rc = gather_blocks((char*)c->brec_p + (size_t)q * BREC_STRIDE * 16, 16))) return rc;
             if ((rc = gather_blocks(c->side_p, sizeof(SideList)))) return rc;
             ApplyArgs a;
@@ -1099,29 +1125,52 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
             a.xsrc = X0; a.xdst = X1; a.dim = 1; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr; a.se_part = se_row;
             a.lead = boff; a.last = boff + nloc - 1; a.step_model = -1; a.step_lw = nullptr;
             a.nstage = c->opt_stage ? 1 : 0;
-            const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), sizeof(ResolveSmem));
-            if (cfg->resample_fn == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), nloc, NT, xshm, a, c->st, c->brec_p, c->side_p, boff, B);
-            else LAUNCH(c, "k_apply<stratified>(+resolve<P>)", (k_apply<0, true>), nloc, NT, xshm, a, c->st, c->brec_p, c->side_p, boff, B);
+            const size_t xshm = std::max((size_t)a.nstage * CAPX * sizeof(double), inres ? sizeof(ResolveSmem) : (size_t)0);
+            if (inres) {
+                if (cfg->resample_fn == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>(+resolve<P>)", (k_apply<1, true>), nloc, NT, xshm, a, c->st, c->brec_p, c->side_p, boff, B);
+                else LAUNCH(c, "k_apply<stratified>(+resolve<P>)", (k_apply<0, true>), nloc, NT, xshm, a, c->st, c->brec_p, c->side_p, boff, B);
+            } else {
+                LAUNCH(c, "k_resolve_all<P>", k_resolve_all<MODE_P>, 1, NTR, 0, c->w, N, B, c->brec_p, c->side_p, c->cin, c->ain_w, c->ain_p, c->st);
+                if (cfg->resample_fn == BSSM_SYSTEMATIC) LAUNCH(c, "k_apply<systematic>", (k_apply<1, false>), nloc, NT, xshm, a, c->st, nullptr, nullptr, boff, B);
+                else LAUNCH(c, "k_apply<stratified>", (k_apply<0, false>), nloc, NT, xshm, a, c->st, nullptr, nullptr, boff, B);
+            }
             HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
             if ((rc = sync())) return rc;
             // (4) the resampled particles: this rank produced the outputs [out_lo, out_hi); owners are cut at multiples of N / world
-            long long mine[2] = {h.out_lo, h.out_hi};
-            std::vector<long long> all((size_t)2 * W), scnt((size_t)W), rcnt((size_t)W);
-            SHCHK(sh->all_gather(sh->user, mine, all.data(), 16));
+            // ... with this rank's status riding along: a rank that failed (its run state carries an error flag, its kernels returned
+            // early) is seen by every rank HERE, and all of them leave the loop together instead of one returning while the others
+            // wait in the next collective.  The tiling check is made on the gathered ranges, so every rank reaches the same verdict.
+            long long mine[3] = {h.out_lo, h.out_hi, (long long)(h.flags | (h.dead ? 0x100u : 0u))};
+            std::vector<long long> all((size_t)3 * W), scnt((size_t)W), rcnt((size_t)W);
+            if ((rc = gather_host(mine, all.data(), 24))) return rc;
             auto overlap = [](long long a0, long long a1, long long b0, long long b1) { const long long l = std::max(a0, b0), r = std::min(a1, b1); return r > l ? r - l : 0LL; };
-            long long tot_recv = 0;
+            bool any_fail = false, tiles = true;
+            long long edge = 0;
             for (int r2 = 0; r2 < W; r2++) {
+                any_fail = any_fail || all[3 * r2 + 2] != 0;
+                tiles = tiles && all[3 * r2] == edge && all[3 * r2 + 1] >= edge;      // rank r2's outputs start where rank r2 - 1's ended
+                edge = all[3 * r2 + 1];
                 scnt[r2] = overlap(mine[0], mine[1], (long long)r2 * cnt, (long long)(r2 + 1) * cnt);
-                rcnt[r2] = overlap(all[2 * r2], all[2 * r2 + 1], lo, lo + cnt);
-                tot_recv += rcnt[r2];
+                rcnt[r2] = overlap(all[3 * r2], all[3 * r2 + 1], lo, lo + cnt);
             }
-            if (tot_recv != cnt) { g_err = "bssm_pf_run_sharded: the ranks' output ranges do not tile the particles"; return BSSM_ERR_ARG; }
+            if (any_fail) { for (int r2 = 0; r2 < W; r2++) h.flags |= (uint32_t)(all[3 * r2 + 2] & 0xff); break; }      // every rank: same decision
+            if (!tiles || edge != N) { g_err = "bssm_pf_run_sharded: the ranks' output ranges do not tile the particles"; return BSSM_ERR_ARG; }
             const long long nsend = mine[1] - mine[0];
-            if ((long long)xsend.size() < nsend) xsend.resize((size_t)nsend);
-            if (nsend > 0) HIPCHK(hipMemcpyAsync(xsend.data(), X1 + mine[0], (size_t)nsend * 8, hipMemcpyDeviceToHost, c->stream));
-            if ((rc = sync())) return rc;
-            SHCHK(sh->exchange(sh->user, xsend.data(), scnt.data(), xrecv.data(), rcnt.data()));
-            HIPCHK(hipMemcpyAsync(X1 + lo, xrecv.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
+            if (devbuf) {
+                // straight from the resampled particles on this GPU into a device staging area (the send and receive ranges of X1 overlap),
+                // then into this rank's slice
+                double* stage = c->auxlw;
+                if ((rc = sync())) return rc;
+                SHCHK(sh->exchange(sh->user, X1 + mine[0], scnt.data(), stage, rcnt.data()));
+                if ((rc = sync())) return rc;
+                HIPCHK(hipMemcpyAsync(X1 + lo, stage, (size_t)cnt * 8, hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                if ((long long)xsend.size() < nsend) xsend.resize((size_t)nsend);
+                if (nsend > 0) HIPCHK(hipMemcpyAsync(xsend.data(), X1 + mine[0], (size_t)nsend * 8, hipMemcpyDeviceToHost, c->stream));
+                if ((rc = sync())) return rc;
+                SHCHK(sh->exchange(sh->user, xsend.data(), scnt.data(), xrecv.data(), rcnt.data()));
+                HIPCHK(hipMemcpyAsync(X1 + lo, xrecv.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
+            }
             if ((rc = sync())) return rc;
         } else {
             LAUNCH(c, "k_carry", k_carry, nloc, NT, 0, X0, X1, c->w, N, 1, se_row, c->st, boff);
@@ -1133,7 +1182,15 @@ extern "C" int bssm_pf_run_sharded(bssm_ctx* c, const bssm_pf_config* cfg, const
     {
         HIPCHK(hipMemcpy2DAsync(hsend.data(), (size_t)nloc * 8, separt + boff, (size_t)B * 8, (size_t)nloc * 8, (size_t)(T + 1), hipMemcpyDeviceToHost, c->stream));
         if ((rc = sync())) return rc;
-        if (sh->all_gather(sh->user, hsend.data(), hrecv.data(), (long long)((size_t)(T + 1) * nloc * 8)) != 0) { g_err = "bssm_pf_run_sharded: a collective callback failed"; return BSSM_ERR_ARG; }
+        const size_t seb = (size_t)(T + 1) * nloc * 8;
+        if (devbuf) {
+            void* dse; if ((rc = pool_get(c, "sh_se", seb * (W + 1), &dse))) return rc;
+            HIPCHK(hipMemcpyAsync(dse, hsend.data(), seb, hipMemcpyHostToDevice, c->stream));
+            if ((rc = sync())) return rc;
+            if (sh->all_gather(sh->user, dse, (char*)dse + seb, (long long)seb) != 0) { g_err = "bssm_pf_run_sharded: a collective callback failed"; return BSSM_ERR_ARG; }
+            if ((rc = sync())) return rc;
+            HIPCHK(hipMemcpy(hrecv.data(), (char*)dse + seb, seb * W, hipMemcpyDeviceToHost));
+        } else if (sh->all_gather(sh->user, hsend.data(), hrecv.data(), (long long)seb) != 0) { g_err = "bssm_pf_run_sharded: a collective callback failed"; return BSSM_ERR_ARG; }
         std::vector<double> full((size_t)(T + 1) * B);
         const double* rv = (const double*)hrecv.data();
         for (int r2 = 0; r2 < W; r2++) for (int i = 0; i <= T; i++)

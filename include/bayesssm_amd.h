@@ -217,13 +217,23 @@ int bssm_pf_weigh_resample(bssm_ctx* ctx, long long n, const double* log_weights
  * and every rank resolves the exact sums redundantly, so the result is bit-identical to bssm_pf_run on one GPU.
  * The collectives are the caller's (host-staged callbacks: torch.distributed / RCCL / MPI); they return 0 on success.
  * Limits of the prototype: bootstrap filter, scalar-state Gaussian models, stratified / systematic resampling,
- * N a multiple of world x 2048 and at most 2^20, no histories.  Every rank returns the full result. */
+ * N a multiple of world x 2048 and at most 2^22 IN ALL (the block-record workspace of this build: every rank resolves the records
+ * of all blocks -- inside the consuming kernels up to 2^20, by one 1024-thread workgroup per rank above), no histories.  Every rank
+ * returns the full result.  A rank whose run state carries an error is noticed by all ranks at exchange (4) of that observation (its
+ * status rides along) and all leave together; a callback that fails returns at once on that rank -- the collective layer's own
+ * time-out is what ends the other ranks' wait then. */
 typedef struct {
     int rank, world;
     int (*all_gather)(void* user, const void* send, void* recv, long long bytes_per_rank);       /* recv holds world x bytes_per_rank */
     int (*exchange)(void* user, const double* send, const long long* send_counts /* [world] */,
                     double* recv, const long long* recv_counts /* [world] */);                    /* all-to-all of doubles, pieces in rank order */
     void* user;
+    /* 0: the callbacks receive HOST pointers (the library stages device data through host memory: gloo, MPI, the one-GPU tests).
+     * 1: they receive DEVICE pointers of the context's GPU (RCCL: ncclAllGather / grouped ncclSend + ncclRecv, no host copies).  The
+     *    library has synchronised the context's stream before a call; the callback either completes before it returns or enqueues
+     *    its work on bssm_ctx_stream(ctx), which the library synchronises again after the call.  all_gather may be called IN PLACE
+     *    (send == recv + rank x bytes_per_rank), as ncclAllGather allows. */
+    int device_buffers;
 } bssm_shard;
 int bssm_pf_run_sharded(bssm_ctx* ctx, const bssm_pf_config* cfg, const bssm_shard* shard, bssm_pf_result* res);
 
