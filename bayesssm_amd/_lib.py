@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BAYESSSM_AMD_LIB") or os.path.join(_HERE, "libbayesssm_amd.so")
 
 OK, ERR_NEGATIVE, ERR_ZERO_SUM, ERR_LENGTH, ERR_ARG, ERR_HIP, ERR_CAPACITY = range(7)
-MODEL = {"lg": 0, "ar1sin": 1, "sir": 2}
+MODEL = {"lg": 0, "ar1sin": 1, "sir": 2, "lgmv": 3}
 ALGORITHM = {"BPF": 0, "APF": 1, "RMPF": 2}
 RESAMPLE_ALGORITHM = {"SIS": 0, "SISR": 1, "SISAR": 2}
 RESAMPLE_FN = {"stratified": 0, "systematic": 1, "multinomial": 2, "multinomial_r": 3}
@@ -129,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_ctx_set_option", "bssm_ctx_get_stamps", "bssm_pmmh_chain",
     "bssm_resample_multinomial_r",
     "bssm_pf_run_batch", "bssm_pf_batch_max_particles", "bssm_pmmh_chains_batch", "bssm_pmmh_chain_draws",
-    "bssm_pf_run_sharded", "bssm_pf_weigh_resample", "bssm_ctx_fused_stats", "bssm_ctx_fused_stamps",
+    "bssm_pf_run_sharded", "bssm_pf_weigh_resample", "bssm_ctx_fused_stats", "bssm_ctx_fused_stamps", "bssm_dump_normals_mv",
 ]
 
 

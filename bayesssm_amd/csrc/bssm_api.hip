@@ -15,6 +15,7 @@
 #include <algorithm>
 #include "kernels.hip.h"
 #include "fused.hip.h"
+#include "mv.hip.h"
 #include <atomic>
 #include "../../include/bayesssm_amd.h"
 
@@ -137,7 +138,7 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
     if (!out) ARGFAIL("bssm_ctx_create: out is NULL");
     *out = nullptr;
     if (max_particles <= 0) ARGFAIL("bssm_ctx_create: max_particles must be positive");
-    if (max_dim < 1 || max_dim > 2) ARGFAIL("bssm_ctx_create: max_dim must be 1 or 2");
+    if (max_dim < 1 || max_dim > MVD) ARGFAIL("bssm_ctx_create: max_dim must be 1 .. 8");
     const long long B = (max_particles + EB - 1) / EB;
     if (B > MAXB) { g_err = "bssm_ctx_create: max_particles exceeds 2^22 (scan workspace limit of this build)"; return BSSM_ERR_CAPACITY; }
     int ndev = 0;
@@ -890,9 +891,164 @@ static int pf_run_impl(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* r
     return BSSM_OK;
 }
 
+
+// ---- multivariate linear-Gaussian family (mv.hip.h): bootstrap filter, d <= 8 ---------------------------------------------
+// cfg->theta: the packed block  d, p, m0[d], L0[d d], A[d d], b[d], L[d d], c0, H[p d], h0[p], sd[p];  cfg->y: [T][p] row-major
+// (unused when p == 0);  injected draws: z_init [d][N], z_trans [calls][d][N] (component-major), u_res as for the scalar models.
+static int pf_run_mv(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* res)
+{
+    const long long N = cfg->num_particles;
+    const int T = cfg->T;
+    if (N <= 0) ARGFAIL("num_particles must be a positive count");
+    if (T < 0) ARGFAIL("bssm_pf_run: T must be >= 0");
+    if (N > c->cap) { g_err = "bssm_pf_run: num_particles exceeds context capacity"; return BSSM_ERR_CAPACITY; }
+    if (!cfg->theta || cfg->n_theta < 2) ARGFAIL("bssm_pf_run: the multivariate model needs its packed parameter block");
+    MvPar mp; mp.P = nullptr; mp.d = (int)cfg->theta[0]; mp.p = (int)cfg->theta[1];
+    const int d = mp.d, p = mp.p;
+    if (d < 1 || d > MVD || p < 0 || p > MVD) ARGFAIL("bssm_pf_run: multivariate model: 1 <= d <= 8, 0 <= p <= 8");
+    if (cfg->n_theta != mp.o_lsd()) ARGFAIL("bssm_pf_run: multivariate model: parameter block has the wrong length");
+    if (d > c->max_dim) { g_err = "bssm_pf_run: the context was created with a smaller max_dim than this model's state dimension"; return BSSM_ERR_CAPACITY; }
+    if (cfg->algorithm != BSSM_BPF) ARGFAIL("bssm_pf_run: the multivariate family runs the bootstrap filter");
+    if (cfg->resample_algorithm < 0 || cfg->resample_algorithm > 2) ARGFAIL("bssm_pf_run: unknown resample_algorithm");
+    if (cfg->resample_fn != BSSM_STRATIFIED && cfg->resample_fn != BSSM_SYSTEMATIC) ARGFAIL("bssm_pf_run: the multivariate family resamples stratified / systematic");
+    if (T > 0 && p > 0 && !cfg->y) ARGFAIL("bssm_pf_run: y is NULL");
+    if (!res->state_est || !res->ess || !res->loglike || (T > 0 && !res->loglike_history)) ARGFAIL("bssm_pf_run: result buffers missing");
+    for (int i = 0; i < T * p; i++) if (!isfinite(cfg->y[i])) ARGFAIL("Assertion on 'y' failed: Contains missing values");
+    for (int k = 0; k < p; k++) if (!(cfg->theta[mp.o_sd() + k] > 0)) ARGFAIL("bssm_pf_run: multivariate model: observation sd must be positive");
+    if (cfg->obs_times) { int prev = 1; for (int i = 0; i < T; i++) { if (cfg->obs_times[i] < prev) ARGFAIL("Assertion on 'obs_times' failed: Must be sorted and >= 1"); prev = cfg->obs_times[i]; } }
+    HIPCHK(hipSetDevice(c->device));
+    const int B = (int)((N + EB - 1) / EB);
+    const double dN = (double)N;
+    const int resample_algorithm = cfg->resample_algorithm;
+    double threshold = cfg->threshold;
+    if (isnan(threshold)) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;
+    int max_trans = 0, max_res = 0;
+    bssm_pf_noise_shape(BSSM_BPF, T, cfg->obs_times, &max_trans, &max_res);
+    const long long u_stride = (cfg->resample_fn == BSSM_SYSTEMATIC) ? 1 : N;
+    void *d_ess, *d_llh, *d_se, *d_separt, *d_resampled, *d_anc, *d_P, *d_y = nullptr, *d_ph = nullptr, *d_wh = nullptr, *d_zi = nullptr, *d_zt = nullptr, *d_ur = nullptr;
+    int rc;
+    if ((rc = pool_get(c, "ess", (size_t)(T + 1) * 8, &d_ess))) return rc;
+    if ((rc = pool_get(c, "llh", (size_t)(T + 1) * 8, &d_llh))) return rc;
+    if ((rc = pool_get(c, "se", (size_t)(T + 1) * d * 8, &d_se))) return rc;
+    if ((rc = pool_get(c, "separt", (size_t)(T + 1) * B * d * 8, &d_separt))) return rc;
+    if ((rc = pool_get(c, "resampled", (size_t)(T + 1) * 4, &d_resampled))) return rc;
+    const long long anc_stride = cfg->return_ancestors ? N : 0;
+    if (cfg->return_ancestors && !res->ancestors) ARGFAIL("bssm_pf_run: ancestors buffer missing");
+    if ((rc = pool_get(c, "anc", (size_t)(cfg->return_ancestors ? std::max(max_res, 1) : 1) * N * 4, &d_anc))) return rc;
+    if (cfg->return_particles) {
+        if (!res->particles_history || !res->weights_history) ARGFAIL("bssm_pf_run: history buffers missing");
+        if ((rc = pool_get(c, "ph", (size_t)(T + 1) * N * d * 8, &d_ph))) return rc;
+        if ((rc = pool_get(c, "wh", (size_t)(T + 1) * N * 8, &d_wh))) return rc;
+    }
+    std::vector<double> hp((size_t)mp.size());
+    memcpy(hp.data(), cfg->theta, (size_t)mp.o_lsd() * 8);
+    for (int k = 0; k < p; k++) hp[(size_t)mp.o_lsd() + k] = log(cfg->theta[mp.o_sd() + k]);      // (taken on the host, like log(sigma_y) of the scalar models)
+    if ((rc = pool_get(c, "mv_par", hp.size() * 8, &d_P))) return rc;
+    HIPCHK(hipMemcpyAsync(d_P, hp.data(), hp.size() * 8, hipMemcpyHostToDevice, c->stream));
+    mp.P = (const double*)d_P;
+    if (p > 0 && T > 0) { if ((rc = pool_get(c, "mv_y", (size_t)T * p * 8, &d_y))) return rc; HIPCHK(hipMemcpyAsync(d_y, cfg->y, (size_t)T * p * 8, hipMemcpyHostToDevice, c->stream)); }
+    if (cfg->z_init) { if ((rc = pool_get(c, "zi", (size_t)N * d * 8, &d_zi))) return rc; HIPCHK(hipMemcpyAsync(d_zi, cfg->z_init, (size_t)N * d * 8, hipMemcpyHostToDevice, c->stream)); }
+    if (cfg->z_trans && max_trans > 0) { if ((rc = pool_get(c, "zt", (size_t)max_trans * N * d * 8, &d_zt))) return rc; HIPCHK(hipMemcpyAsync(d_zt, cfg->z_trans, (size_t)max_trans * N * d * 8, hipMemcpyHostToDevice, c->stream)); }
+    if (cfg->u_res && max_res > 0) { if ((rc = pool_get(c, "ur", (size_t)max_res * u_stride * 8, &d_ur))) return rc; HIPCHK(hipMemcpyAsync(d_ur, cfg->u_res, (size_t)max_res * u_stride * 8, hipMemcpyHostToDevice, c->stream)); }
+    HIPCHK(hipStreamSynchronize(c->stream));                 // (hp lives on this stack frame)
+    HIPCHK(hipMemsetAsync(d_separt, 0, (size_t)(T + 1) * B * d * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_ess, 0, (size_t)(T + 1) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_llh, 0, (size_t)(T + 1) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d_resampled, 0, (size_t)(T + 1) * 4, c->stream));
+    const PhiloxKey key = make_key(cfg->seed, cfg->stream);
+    double* X0 = c->x0; double* X1 = c->x1;
+    double* separt = (double*)d_separt;
+    c->gmax_cur = nullptr;
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    LAUNCH(c, "k_reset_state", k_reset_state, 1, 1, 0, c->st);
+    {
+        MvNoise ns; ns.arr = (const double*)d_zi; ns.key = key; ns.purpose = DRAW_INIT; ns.call = 0;
+        LAUNCH(c, "k_init_mv", k_init_mv, B, NT, 0, X0, N, mp, ns, separt);
+        if (cfg->return_particles) {
+            std::vector<double> w0((size_t)N, 1.0 / dN);
+            HIPCHK(hipMemcpyAsync(d_wh, w0.data(), (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpyAsync(d_ph, X0, (size_t)N * d * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    int ktrans = 0, prev_t = 0;
+    for (int i = 1; i <= T; i++) {                                                        // R/particle_filter_core.R:123
+        const int ot = cfg->obs_times ? cfg->obs_times[i - 1] : i;
+        const int gap = ot - prev_t;                                                      // :124
+        prev_t = ot;
+        const double* yrow = p > 0 ? (const double*)d_y + (size_t)(i - 1) * p : nullptr;
+        auto noise = [&](int k) { MvNoise ns; ns.arr = d_zt ? (const double*)d_zt + (size_t)k * N * d : nullptr; ns.key = key; ns.purpose = DRAW_TRANS; ns.call = (uint32_t)k; return ns; };
+        for (int step = 1; step <= gap; step++) {                                         // :125-136, the last one fused with weight_fn (:177-183)
+            if (step == gap) LAUNCH(c, "k_step_mv<trans+weight>", (k_step_mv<true, true>), B, NTS, 0, X0, c->lw, N, mp, yrow, noise(ktrans), c->pm, c->ps, c->pq, (unsigned long long*)nullptr);
+            else LAUNCH(c, "k_step_mv<trans>", (k_step_mv<true, false>), B, NTS, 0, X0, c->lw, N, mp, yrow, noise(ktrans), c->pm, c->ps, c->pq, (unsigned long long*)nullptr);
+            ktrans++;
+        }
+        if (gap <= 0) LAUNCH(c, "k_step_mv<weight>", (k_step_mv<false, true>), B, NTS, 0, X0, c->lw, N, mp, yrow, noise(0), c->pm, c->ps, c->pq, (unsigned long long*)nullptr);
+        double* se_row = separt + (size_t)i * B * d;
+        ResampleLaunch r;
+        r.d_lw = c->lw; r.plan = PLAN_PF; r.check_degenerate = 1; r.obs_i = i; r.resample_algorithm = resample_algorithm; r.threshold = threshold;
+        r.d_ess = (double*)d_ess; r.d_llh = (double*)d_llh; r.d_resampled = (int*)d_resampled;
+        r.d_w = c->w; r.nw = N; r.n = (int)N; r.kind = cfg->resample_fn; r.d_u = (const double*)d_ur; r.u_stride = u_stride; r.key = key;
+        r.d_anc = (int*)d_anc; r.anc_stride = anc_stride; r.d_cum = nullptr;
+        r.xsrc = nullptr; r.xdst = nullptr; r.dim = 1; r.xstride = 0; r.auxsrc = nullptr; r.auxdst = nullptr; r.se_part = nullptr;
+        launch_scan_and_apply(c, r);                                                      // :204-224: ancestors only
+        LAUNCH(c, "k_gather_mv", k_gather_mv, B, NT, 0, (const int*)d_anc, anc_stride, N, d, X0, X1, se_row, c->st);        // particles[indices, ]
+        if (resample_algorithm != BSSM_SISR) LAUNCH(c, "k_carry_mv", k_carry_mv, B, NT, 0, X0, X1, c->w, N, d, se_row, c->st);
+        std::swap(X0, X1);
+        if (cfg->return_particles)
+            LAUNCH(c, "k_record_history", k_record_history, (unsigned)((N + 255) / 256), 256, 0, X0, c->w, N, d,
+                   (double*)d_ph + (size_t)i * N * d, (double*)d_wh + (size_t)i * N, c->st);
+    }
+    LAUNCH(c, "k_reduce_state_est", k_reduce_state_est, T + 1, NT, 0, separt, B, d, (double*)d_se);
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipGetLastError());
+    DevState h;
+    HIPCHK(hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(res->state_est, d_se, (size_t)(T + 1) * d * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(res->ess, d_ess, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (T > 0) HIPCHK(hipMemcpyAsync(res->loglike_history, d_llh, (size_t)T * 8, hipMemcpyDeviceToHost, c->stream));
+    if (res->resampled && T > 0) HIPCHK(hipMemcpyAsync(res->resampled, d_resampled, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (res->device_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *res->device_ms = ms; }
+    res->ess[0] = 1.0 / (dN * ((1.0 / dN) * (1.0 / dN)));
+    *res->loglike = h.loglike;
+    if (res->early_return_step) *res->early_return_step = h.dead;
+    if (res->n_res_calls) *res->n_res_calls = h.res_calls;
+    if (res->scan_stats) { res->scan_stats[0] = h.stat_hard_blocks; res->scan_stats[1] = h.stat_serial_walks; res->scan_stats[2] = h.stat_literal_terms; }
+    if (h.dead) {   // the reference returns at once (:189-202): numeric() zeros for a scalar state, matrix(NA) rows otherwise (:90-97)
+        const double se_init = (d > 1) ? (double)NAN : 0.0;
+        for (int i = h.dead; i <= T; i++) { res->ess[i] = 0.0; for (int k = 0; k < d; k++) res->state_est[(size_t)i * d + k] = se_init; }
+        for (int i = h.dead; i < T; i++) res->loglike_history[i] = 0.0;
+    }
+    if (h.flags) { const int st = flags_to_status(h.flags); if (st != BSSM_ERR_ARG) g_err = bssm_status_string(st); return st; }
+    if (cfg->return_ancestors && h.res_calls > 0) HIPCHK(hipMemcpy(res->ancestors, d_anc, (size_t)h.res_calls * N * 4, hipMemcpyDeviceToHost));
+    if (cfg->return_particles) {
+        const int rows = h.dead ? h.dead : T + 1;
+        HIPCHK(hipMemcpy(res->particles_history, d_ph, (size_t)rows * N * d * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(res->weights_history, d_wh, (size_t)rows * N * 8, hipMemcpyDeviceToHost));
+    }
+    return BSSM_OK;
+}
+
+extern "C" int bssm_dump_normals_mv(bssm_ctx* c, unsigned long long seed, unsigned long long stream, int purpose, int call,
+                                    long long N, int d, double* out /* [d][N] */)
+{
+    if (!c || !out || N <= 0 || d < 1 || d > MVD) ARGFAIL("bssm_dump_normals_mv: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    void* dd; int rc = pool_get(c, "dump", (size_t)N * d * 8, &dd); if (rc) return rc;
+    const long long pairs = (N + 1) / 2;
+    hipLaunchKernelGGL(k_dump_normals_mv, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, c->stream, make_key(seed, stream), (uint32_t)purpose, (uint32_t)call, N, d, (double*)dd);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dd, (size_t)N * d * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BSSM_OK;
+}
+
 extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* res)
 {
     if (!c) ARGFAIL("bssm_pf_run: NULL argument");
+    if (cfg && res && cfg->model == BSSM_MODEL_LGMV) return pf_run_mv(c, cfg, res);
     // the fused path needs the device's token (one fused run at a time); without it the run takes the multi-launch path
     const int dev = c->device & 63;
     int expected = 0;

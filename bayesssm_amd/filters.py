@@ -39,11 +39,21 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
     if not (isinstance(num_particles, (int, np.integer)) and num_particles > 0):
         raise ValueError("Assertion on 'num_particles' failed: Must be a positive count")      # assert_count :33
     y = np.ascontiguousarray(y, dtype=np.float64)
-    if y.ndim != 1:
-        raise ValueError("this build supports scalar observations (y a vector)")
+    mv = (model == "lgmv")
+    if mv:                                                 # y: a vector (one column, :70) or a T x p matrix
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        mv_d, mv_p = int(theta[0]), int(theta[1])
+        if y.ndim == 1:
+            y = y.reshape(-1, 1)
+        if y.ndim != 2 or (mv_p > 0 and y.shape[1] != mv_p):
+            raise ValueError("y must be a vector or a T x %d matrix for this model" % mv_p)
+        if mv_p == 0:
+            y = np.zeros((y.shape[0], 0))
+    elif y.ndim != 1:
+        raise ValueError("this build supports scalar observations (y a vector) for the scalar models")
     if not np.all(np.isfinite(y)):
         raise ValueError("Assertion on 'y' failed: Contains missing values")                    # assert_numeric :69
-    T = int(y.size)
+    T = int(y.shape[0])
     N = int(num_particles)
     ot = None
     if obs_times is not None:
@@ -51,7 +61,7 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
         if ot.size != T or (T and (ot[0] < 1 or np.any(np.diff(ot) < 0))):
             raise ValueError("Assertion on 'obs_times' failed")                                  # assert_integerish :73
     theta = np.ascontiguousarray(theta, dtype=np.float64)
-    dim = models.dim_of(model)
+    dim = mv_d if mv else models.dim_of(model)
     ctx = ctx.require(N, dim) if ctx is not None else _lib.default_context(N, dim=dim)
     max_trans, max_res = noise_shape(algorithm, T, ot)
     state_est = np.zeros((T + 1, dim)) if dim > 1 else np.zeros(T + 1)
@@ -73,7 +83,7 @@ def particle_filter_core(y, num_particles, model, theta, algorithm="BPF", obs_ti
         if model != "sir":       # SIR draws a data-dependent number of variates: always the device generator
             zi = np.ascontiguousarray(draws["z_init"], dtype=np.float64)
             zt = np.ascontiguousarray(draws["z_trans"], dtype=np.float64)
-            assert zi.size >= N and zt.size >= max_trans * N
+            assert zi.size >= N * (dim if mv else 1) and zt.size >= max_trans * N * (dim if mv else 1)       # (lgmv: [d][N] per call, component-major)
     zmv = umv = None
     if draws is not None and algorithm == "RMPF":
         zmv = np.ascontiguousarray(draws["z_move"], dtype=np.float64)
@@ -200,6 +210,10 @@ def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
     r_seed = kwargs.pop("r_seed", None)
     ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
     model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
+    if model == "lgmv":                      # multivariate linear-Gaussian family: the descriptor packs its matrices for this parameter draw
+        theta = init_fn.owner.pack(kwargs)
+        return particle_filter_core(y, num_particles, model, theta, "BPF", obs_times, resample_algorithm, resample_fn,
+                                    threshold, return_particles, **ctl)
     theta = models.theta_from_kwargs((init_fn, transition_fn, log_likelihood_fn), kwargs)
     if r_seed is not None:
         return _r_seeded_bootstrap(y, num_particles, model, theta, obs_times, resample_algorithm, resample_fn, threshold,

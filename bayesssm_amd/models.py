@@ -80,6 +80,73 @@ class MoveFn:
         return ["particle", "y", "sigma_y"]
 
 
+class LinearGaussianMV:
+    """Multivariate linear-Gaussian family on the device (state dimension d <= 8, observation dimension p <= 8):
+
+        init_fn           x0 = m0 + L0 z               (the reference's  matrix(rnorm(N d), ncol = d)  shifted and scaled)
+        transition_fn     x' = A x + b + L z           L lower triangular: a Cholesky factor of the state noise covariance
+        log_likelihood_fn p == 0: the constant c0      (tests/testthat/test-bootstrap_filter.R:211-230: rep(1, nrow(particles)))
+                          p >  0: sum_k dnorm(y_k, h0_k + (H x)_k, sd_k, log = TRUE)
+
+    Fixed pieces are given to the constructor (m0, P0 or L0, A, b, Q or L, c0, H, h0, sd); pieces that depend on sampled
+    parameters come from `build(**params) -> dict of pieces` (e.g. the reference's multi-dimensional PMMH case,
+    tests/testthat/test-pmmh.R:619-668:  linear_gaussian_mv(2, build=lambda phi: {"b": [phi, phi]}, param_names=("phi",))).
+    The three descriptors carry the parameter names, so bootstrap_filter / pmmh take them as they take the scalar models."""
+
+    def __init__(self, d, p=0, build=None, param_names=(), **pieces):
+        import numpy as np
+        if not (1 <= int(d) <= 8 and 0 <= int(p) <= 8):
+            raise ValueError("linear_gaussian_mv: 1 <= d <= 8 and 0 <= p <= 8")
+        self.name, self.dim, self.p = "lgmv", int(d), int(p)
+        self.build, self.param_order, self.constants = build, tuple(param_names), ()
+        self.pieces = {"m0": np.zeros(self.dim), "L0": np.eye(self.dim), "A": np.eye(self.dim), "b": np.zeros(self.dim), "L": np.eye(self.dim),
+                       "c0": 0.0, "H": np.eye(self.p, self.dim), "h0": np.zeros(self.p), "sd": np.ones(self.p)}
+        self._set(pieces)
+        self.init_fn = ModelFn("lgmv", "init", ())
+        self.transition_fn = ModelFn("lgmv", "transition", self.param_order)
+        self.log_likelihood_fn = ModelFn("lgmv", "log_likelihood", ())
+        for fn in (self.init_fn, self.transition_fn, self.log_likelihood_fn):
+            fn.owner = self
+
+    def _set(self, pieces, into=None):
+        import numpy as np
+        tgt = self.pieces if into is None else into
+        for k, v in pieces.items():
+            if k == "P0":
+                tgt["L0"] = np.linalg.cholesky(np.atleast_2d(np.asarray(v, dtype=np.float64)))
+            elif k == "Q":
+                tgt["L"] = np.linalg.cholesky(np.atleast_2d(np.asarray(v, dtype=np.float64)))
+            elif k in self.pieces:
+                tgt[k] = float(v) if k == "c0" else np.asarray(v, dtype=np.float64)
+            else:
+                raise TypeError("linear_gaussian_mv: unknown piece %r" % k)
+
+    def pack(self, params):
+        """the packed parameter block of include/bayesssm_amd.h (BSSM_MODEL_LGMV) for one parameter draw"""
+        import numpy as np
+        q = dict(self.pieces)
+        if self.build is not None:
+            missing = [k for k in self.param_order if k not in params]
+            if missing:
+                raise TypeError('argument "%s" is missing, with no default' % missing[0])
+            self._set(self.build(**{k: float(params[k]) for k in self.param_order}), into=q)
+        d, p = self.dim, self.p
+        shapes = {"m0": (d,), "L0": (d, d), "A": (d, d), "b": (d,), "L": (d, d), "H": (p, d), "h0": (p,), "sd": (p,)}
+        parts = [np.array([d, p], dtype=np.float64)]
+        for k in ("m0", "L0", "A", "b", "L"):
+            parts.append(np.broadcast_to(np.asarray(q[k], dtype=np.float64), shapes[k]).reshape(-1))
+        parts[2] = np.tril(parts[2].reshape(d, d)).reshape(-1)          # (lower triangles: what a Cholesky factor is)
+        parts[5] = np.tril(parts[5].reshape(d, d)).reshape(-1)
+        parts.append(np.array([q["c0"]], dtype=np.float64))
+        for k in ("H", "h0", "sd"):
+            parts.append(np.broadcast_to(np.asarray(q[k], dtype=np.float64), shapes[k]).reshape(-1))
+        return np.ascontiguousarray(np.concatenate(parts))
+
+
+def linear_gaussian_mv(d, p=0, build=None, param_names=(), **pieces):
+    return LinearGaussianMV(d, p, build, param_names, **pieces)
+
+
 def linear_gaussian():
     """x0 ~ N(0,1); x' = phi x + N(0, sigma_x); y ~ N(x, sigma_y)
     (tests/testthat/test-pmmh_tuning.R:163-173 with free sigma_x, sigma_y; BASELINE C2/C3/C5)."""
@@ -131,4 +198,4 @@ def theta_from_kwargs(fns, kwargs):
 
 
 def dim_of(model_name):
-    return 2 if model_name == "sir" else 1
+    return 2 if model_name == "sir" else 1            # ("lgmv": the dimension is the descriptor's, see filters.particle_filter_core)

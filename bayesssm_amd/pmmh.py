@@ -404,6 +404,8 @@ def run_chain_host(pf, m, init_theta, proposal_cov, transform, priors, rng, retu
 
 def _closure_formals(fn):
     import inspect
+    if hasattr(fn, "formals"):                  # a device model descriptor (the multivariate family): it lists its own arguments
+        return fn.formals()
     return [n for n, q in inspect.signature(fn).parameters.items() if q.kind not in (q.VAR_KEYWORD, q.VAR_POSITIONAL)]
 
 
@@ -472,13 +474,20 @@ def _pmmh_closures(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, 
     if ctx is not None:
         extra["ctx"] = ctx
 
+    device_model = hasattr(init_fn, "owner")        # the multivariate family: the filter runs fused on the device with its own generator
+    calls = {"n": 0, "seed": 0}
+
     def run_pf(theta, n, **over):
+        if device_model:                             # a fresh (seed, stream) per filter run, as every call of the closures draws afresh in R
+            calls["n"] += 1
+            over = dict(over, seed=calls["seed"], stream=calls["n"])
         return pf_wrapper(y, int(n), init_fn, transition_fn, log_likelihood_fn, obs_times=obs_times, return_particles=False,
                           **over, **dict(zip(prior_names, [float(v) for v in theta])), **extra)
 
     local, extras_out = {}, {}
     for c in mine:                                                    # chain_result (:345-505)
         set_seed(int(seeds[c]))                                       # set.seed(seed) (:346): the resampling stream of this chain
+        calls["seed"], calls["n"] = int(seeds[c]), 0
         rng = np.random.default_rng([int(seeds[c]), 77])
         if verbose:
             print("Running chain %d..." % (c + 1)); print("Running pilot chain for tuning...")
@@ -543,7 +552,7 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     if not (isinstance(num_chains, (int, np.integer)) and num_chains >= 1):
         raise ValueError("Assertion on 'num_chains' failed: Must be >= 1")
     from .closures import is_closure_model
-    if is_closure_model(init_fn, transition_fn, log_likelihood_fn):
+    if is_closure_model(init_fn, transition_fn, log_likelihood_fn) or getattr(init_fn, "model", None) == "lgmv":
         if num_particles is not None or proposal_cov is not None:
             raise ValueError("num_particles / proposal_cov overrides belong to the built-in device models")
         return _pmmh_closures(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors, pilot_init_params,

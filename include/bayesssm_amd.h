@@ -54,6 +54,11 @@ extern "C" {
 #define BSSM_MODEL_AR1SIN 1   /* x' = phi x + sin x + N(0,sx);    y ~ N(x, sy)   README.md:137-146 */
 #define BSSM_MODEL_SIR 2      /* stochastic SIR, state (s, i), Gillespie day, y ~ Poisson(i);
                                  theta = (lambda, gamma, n_total, s0, i0)          vignettes/articles/stochastic-sir-model.Rmd:143-176,285-310 */
+#define BSSM_MODEL_LGMV 3     /* multivariate linear-Gaussian family, state dimension d <= 8, observation dimension p <= 8 (bootstrap filter):
+                               *   x0 = m0 + L0 z;  x' = A x + b + L z;  log g = c0 (p == 0) or sum_k dnorm(y_k, h0_k + (H x)_k, sd_k, log = TRUE)
+                               * theta = the packed block  d, p, m0[d], L0[d d], A[d d], b[d], L[d d], c0, H[p d], h0[p], sd[p]  (row-major matrices),
+                               * y = [T][p] row-major, state_est = [T+1][d]; injected draws z_init [d][N], z_trans [calls][d][N].  Covers the reference's
+                               * multi-dimensional cases (tests/testthat/test-bootstrap_filter.R:211-230, test-pmmh.R:619-668) without the host closures. */
 
 #define BSSM_BPF 0            /* bootstrap_filter  */
 #define BSSM_APF 1            /* auxiliary_filter  */
@@ -267,6 +272,7 @@ int bssm_pf_noise_shape(int algorithm, int T, const int* obs_times, int* max_tra
  * (host output pointers). */
 int bssm_dump_normals(bssm_ctx* ctx, unsigned long long seed, unsigned long long stream,
                       int purpose /* 1 init, 2 transition */, int call, long long n, double* out);
+int bssm_dump_normals_mv(bssm_ctx* ctx, unsigned long long seed, unsigned long long stream, int purpose, int call, long long N, int d, double* out /* [d][N] */);
 int bssm_dump_uniforms(bssm_ctx* ctx, unsigned long long seed, unsigned long long stream,
                        int call, long long n, double* out);
 int bssm_dump_move_draws(bssm_ctx* ctx, unsigned long long seed, unsigned long long stream,

@@ -483,6 +483,123 @@ done:
     return rc;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Multivariate linear-Gaussian family (state dimension d, observation dimension p): the same core loop,
+ * R/particle_filter_core.R:76-116,123-246, with the model functions of bayesssm_amd/csrc/mv.hip.h restated
+ * operation for operation:
+ *   init_fn        x0 = m0 + L0 z                              (matrix(rnorm(N d), ncol = d), :76-88)
+ *   transition_fn  x'_c = ((b_c + A_c0 x_0) + A_c1 x_1 + ...) + L_c0 z_0 + ... + L_cc z_c     (:127)
+ *   weight_fn      p == 0: c0;  else sum_k dnorm(y_k, h0_k + (H x)_k, sd_k, log = TRUE)        (:177-183)
+ * theta: d, p, m0[d], L0[d d], A[d d], b[d], L[d d], c0, H[p d], h0[p], sd[p] (row-major); y [T][p];
+ * particles SoA [d][N]; draws z_init [d][N], z_trans [calls][d][N].  Bootstrap filter only. */
+typedef struct {
+    int N, T, resample_algorithm, resample_fn;
+    double threshold;
+    const double *theta; const double *y; const int *obs_times;
+    const double *z_init, *z_trans, *u_res;
+    double *state_est, *ess, *loglike_history, *loglike;
+    int *ancestors; int *n_res_calls; int *early_return_step; int *resampled;
+    double *particles_hist; double *weights_hist;      /* optional [T+1][N d] (as.numeric of the N x d matrix = component-major), [T+1][N] */
+} orc_pf_mv_args;
+
+int orc_pf_run_mv(orc_pf_mv_args *a)
+{
+    const int N = a->N, T = a->T;
+    if (N <= 0 || T < 0) return ORC_ERR_ARG;
+    const int d = (int)a->theta[0], p = (int)a->theta[1];
+    if (d < 1 || d > 8 || p < 0 || p > 8) return ORC_ERR_ARG;
+    const double *m0 = a->theta + 2, *L0 = m0 + d, *A = L0 + d * d, *b = A + d * d, *L = b + d, *c0 = L + d * d, *H = c0 + 1, *h0 = H + p * d, *sd = h0 + p;
+    const double dN = (double)N;
+    double threshold = a->threshold;
+    if (isnan(threshold)) threshold = (a->resample_algorithm == ORC_SIS) ? INFINITY : (a->resample_algorithm == ORC_SISR) ? dN : dN / 2;   /* :44-50 */
+    const size_t ures_stride = (a->resample_fn == ORC_SYSTEMATIC) ? 1 : (size_t)N;
+    double *x = (double *)malloc(sizeof(double) * N * d), *xold = (double *)malloc(sizeof(double) * N * d);
+    double *lw = (double *)malloc(sizeof(double) * N), *w = (double *)malloc(sizeof(double) * N), *tmp = (double *)malloc(sizeof(double) * N);
+    int *idx = (int *)malloc(sizeof(int) * N);
+    int rc = ORC_OK, ktrans = 0, kres = 0;
+    *a->early_return_step = 0;
+    for (int k = 0; k < N; k++)                                   /* init_fn :76 */
+        for (int c = 0; c < d; c++) {
+            double v = m0[c];
+            for (int j = 0; j <= c; j++) v = v + L0[c * d + j] * a->z_init[(size_t)j * N + k];
+            x[(size_t)c * N + k] = v;
+        }
+    for (int i = 0; i < N; i++) w[i] = 1.0 / dN;                 /* :106 */
+    for (int i = 0; i < N; i++) tmp[i] = w[i] * w[i];
+    a->ess[0] = 1.0 / orc_rsum(N, tmp);                           /* :107 */
+    for (int c = 0; c < d; c++) { for (int i = 0; i < N; i++) tmp[i] = x[(size_t)c * N + i] * w[i]; a->state_est[c] = orc_rsum(N, tmp); }   /* :109-112 */
+    if (a->weights_hist) memcpy(a->weights_hist, w, sizeof(double) * N);
+    if (a->particles_hist) memcpy(a->particles_hist, x, sizeof(double) * N * d);
+    double loglike = 0.0;
+    int prev_t = 0;
+    double xo[8], xn[8];
+    for (int i = 1; i <= T; i++) {                                /* :123 */
+        const int ot = a->obs_times ? a->obs_times[i - 1] : i;
+        const int gap = ot - prev_t;                              /* :124 */
+        for (int step = 1; step <= gap; step++) {                 /* :125-136 */
+            const double *z = a->z_trans + (size_t)ktrans * N * d;
+            for (int k = 0; k < N; k++) {
+                for (int c = 0; c < d; c++) xo[c] = x[(size_t)c * N + k];
+                for (int c = 0; c < d; c++) {
+                    double v = b[c];
+                    for (int j = 0; j < d; j++) v = v + A[c * d + j] * xo[j];
+                    for (int j = 0; j <= c; j++) v = v + L[c * d + j] * z[(size_t)j * N + k];
+                    xn[c] = v;
+                }
+                for (int c = 0; c < d; c++) x[(size_t)c * N + k] = xn[c];
+            }
+            ktrans++;
+        }
+        prev_t = ot;
+        const double *yr = a->y + (size_t)(i - 1) * p;
+        for (int k = 0; k < N; k++) {                             /* weight_fn :177-183 */
+            if (p == 0) lw[k] = c0[0];
+            else {
+                double l = 0.0;
+                for (int q = 0; q < p; q++) {
+                    double m = h0[q];
+                    for (int c = 0; c < d; c++) m = m + H[q * d + c] * x[(size_t)c * N + k];
+                    l = l + orc_dnorm_log(yr[q], m, sd[q], log(sd[q]));
+                }
+                lw[k] = l;
+            }
+        }
+        int all_small = 1;                                        /* :189 */
+        for (int k = 0; k < N; k++) if (!(lw[k] < -1e8)) { all_small = 0; break; }
+        if (all_small) { loglike = -INFINITY; a->loglike_history[i - 1] = -INFINITY; *a->early_return_step = i; goto done; }
+        double max_logw = lw[0];                                  /* :204 */
+        for (int k = 1; k < N; k++) if (lw[k] > max_logw) max_logw = lw[k];
+        for (int k = 0; k < N; k++) tmp[k] = exp(lw[k] - max_logw);          /* :205 */
+        double weight_sum = orc_rsum(N, tmp);                     /* :206 */
+        for (int k = 0; k < N; k++) w[k] = tmp[k] / weight_sum;   /* :207 */
+        loglike = loglike + (max_logw + log(weight_sum) - log(dN));          /* :208 */
+        a->loglike_history[i - 1] = loglike;                      /* :209 */
+        for (int k = 0; k < N; k++) tmp[k] = w[k] * w[k];
+        double ess = 1.0 / orc_rsum(N, tmp);                      /* :211 */
+        a->ess[i] = ess;
+        int should = (a->resample_algorithm == ORC_SIS) ? 0 : (a->resample_algorithm == ORC_SISR) ? 1 : (ess < threshold);   /* :214-218 */
+        if (a->resampled) a->resampled[i - 1] = should;
+        if (should) {                                             /* :220-224 */
+            rc = orc_resample_dispatch(a->resample_fn, N, w, a->u_res + (size_t)kres * ures_stride, idx);
+            if (rc != ORC_OK) goto done;
+            if (a->ancestors) memcpy(a->ancestors + (size_t)kres * N, idx, sizeof(int) * N);
+            kres++;
+            memcpy(xold, x, sizeof(double) * N * d);
+            for (int c = 0; c < d; c++) for (int k = 0; k < N; k++) x[(size_t)c * N + k] = xold[(size_t)c * N + idx[k] - 1];   /* R/resampling.R:40,60 */
+            for (int k = 0; k < N; k++) w[k] = 1.0 / dN;
+            a->ess[i] = dN;                                       /* :223 */
+        }
+        for (int c = 0; c < d; c++) { for (int k = 0; k < N; k++) tmp[k] = x[(size_t)c * N + k] * w[k]; a->state_est[(size_t)i * d + c] = orc_rsum(N, tmp); }   /* :238-240 */
+        if (a->weights_hist) memcpy(a->weights_hist + (size_t)i * N, w, sizeof(double) * N);
+        if (a->particles_hist) memcpy(a->particles_hist + (size_t)i * N * d, x, sizeof(double) * N * d);
+    }
+done:
+    *a->loglike = loglike;
+    *a->n_res_calls = kres;
+    free(x); free(xold); free(lw); free(w); free(tmp); free(idx);
+    return rc;
+}
+
 /* Number of transition_fn calls / resample calls the core will make at most
  * (for sizing the injected-noise arrays). */
 void orc_pf_noise_shape(int algorithm, int T, const int *obs_times, int *max_trans, int *max_res)

@@ -310,3 +310,50 @@ def resample_multinomial_rcpp(n, weights, U):
     if st:
         raise ResampleError(st)
     return out, bool(walker.value)
+
+
+class _PfMvArgs(C.Structure):
+    _fields_ = [("N", C.c_int), ("T", C.c_int), ("resample_algorithm", C.c_int), ("resample_fn", C.c_int), ("threshold", C.c_double),
+                ("theta", C.c_void_p), ("y", C.c_void_p), ("obs_times", C.c_void_p), ("z_init", C.c_void_p), ("z_trans", C.c_void_p),
+                ("u_res", C.c_void_p), ("state_est", C.c_void_p), ("ess", C.c_void_p), ("loglike_history", C.c_void_p), ("loglike", C.c_void_p),
+                ("ancestors", C.c_void_p), ("n_res_calls", C.c_void_p), ("early_return_step", C.c_void_p), ("resampled", C.c_void_p),
+                ("particles_hist", C.c_void_p), ("weights_hist", C.c_void_p)]
+
+
+def pf_run_mv(theta, y, N, z_init, z_trans, u_res, resample_algorithm="SISAR", resample_fn="stratified", threshold=None,
+              obs_times=None, return_ancestors=False, return_particles=False):
+    """.particle_filter_core (R/particle_filter_core.R:19-267) for the multivariate linear-Gaussian family (orc_pf_run_mv):
+    theta = the packed block d, p, m0, L0, A, b, L, c0, H, h0, sd; y [T][p] (any [T][0] array for p == 0);
+    z_init [d][N], z_trans [calls][d][N]."""
+    theta = _d(theta)
+    d, p = int(theta[0]), int(theta[1])
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    T = int(y.shape[0])
+    ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
+    max_trans, max_res = noise_shape("BPF", T, obs_times)
+    z_init, z_trans, u_res = _d(z_init), _d(z_trans), _d(u_res)
+    assert z_init.size >= N * d and z_trans.size >= max_trans * N * d
+    assert u_res.size >= max_res * (1 if resample_fn == "systematic" else N)
+    state_est = np.full((T + 1, d), np.nan) if d > 1 else np.zeros((T + 1, 1))
+    ess, llh, ll = np.zeros(T + 1), np.zeros(max(T, 1)), np.zeros(1)
+    anc = np.zeros((max(max_res, 1), N), dtype=np.int32) if return_ancestors else None
+    ph = np.full((T + 1, N * d), np.nan) if return_particles else None
+    wh = np.full((T + 1, N), np.nan) if return_particles else None
+    nr, ers = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    resampled = np.zeros(max(T, 1), dtype=np.int32)
+    a = _PfMvArgs(N, T, RESAMPLE_ALGORITHM[resample_algorithm], RESAMPLE_FN[resample_fn], float("nan") if threshold is None else float(threshold),
+                  _p(theta), _p(y), _p(ot), _p(z_init), _p(z_trans), _p(u_res), _p(state_est), _p(ess), _p(llh), _p(ll), _p(anc), _p(nr), _p(ers),
+                  _p(resampled), _p(ph), _p(wh))
+    st = lib().orc_pf_run_mv(C.byref(a))
+    if st:
+        raise ResampleError(st)
+    res = {"state_est": state_est if d > 1 else state_est[:, 0], "ess": ess, "loglike": float(ll[0]), "loglike_history": llh[:T], "algorithm": "BPF",
+           "n_res_calls": int(nr[0]), "early_return_step": int(ers[0]), "resampled": resampled[:T]}
+    if int(ers[0]) == 0:
+        res["resample_algorithm"] = resample_algorithm
+    if return_ancestors:
+        res["ancestors"] = anc
+    if return_particles:
+        rows = int(ers[0]) if int(ers[0]) else T + 1
+        res["particles_history"], res["weights_history"] = ph[:rows], wh[:rows]
+    return res
