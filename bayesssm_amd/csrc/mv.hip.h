@@ -10,7 +10,7 @@
 // Only the model evaluation is new: normalisation, log-likelihood, ESS, the resample decision and the exact resampling run in the
 // same kernels as every other filter (k_local / k_apply, which here emit ANCESTORS); particles[indices, ] is then a gather of d
 // coalesced component rows (k_gather_mv).  Particles are SoA [d][N].
-// Arithmetic (fp64, contraction off), fixed so that the oracle can restate it operation for operation:
+// Arithmetic (fp64, contraction off), in one fixed order of operations (the parity tests restate it on the CPU operation for operation):
 //   x'_c = ((b_c + A_c0 x_0) + A_c1 x_1 + ... ) + L_c0 z_0 + ... + L_cc z_c        (left to right)
 #pragma once
 #include "kernels.hip.h"
