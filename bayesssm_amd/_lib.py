@@ -153,6 +153,8 @@ class Context:
         self.device = device
         self.max_particles = max_particles
         self.max_dim = max_dim
+        if os.environ.get("BAYESSSM_AMD_FUSED") is not None:        # A/B switch for the dev tools: the per-context option `fused`
+            check(lib.bssm_ctx_set_option(h, 9, int(os.environ["BAYESSSM_AMD_FUSED"])))
 
     @property
     def handle(self):

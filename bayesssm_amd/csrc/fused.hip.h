@@ -288,13 +288,14 @@ __device__ __forceinline__ uint64_t fz_resolve_duty(SegSmem& sm, ResolveSmem& rs
 #endif
     if (fs.bail) { bail = true; return 0ull; }
     long long lit = 0;
-    // the terms of OTHER blocks are not in HBM in a fused run: any literal re-run (lit > 0) voids the result
+    // the terms of OTHER blocks are not in HBM in a fused run: a literal re-run that reads them (lit >= LIT_FROM_W) voids the result;
+    // terms re-run from a side entry's own copy are fine
     // (cumsum pass: nobody needs the state BEHIND the last block -- its record, the one with the lanes next to cum == 1, stays out of the
     //  walk; the state in front of it is the walk's result)
     const int upto = (MODE == MODE_P) ? B - 1 : B;
     const uint64_t fin = resolve_in_block<MODE, NT, EMIT>(sm, rs, g.ws->brec_priv[MODE], g.ws->side_priv[MODE], B, upto, g.xin, g.N, 1.0, st, true, cin_lds, &lit, &q0, &q1);
     if (EMIT && t == 0) cin_lds[B - 1] = fin;
-    if (lit) fs.bail = 2;
+    if (lit >= LIT_FROM_W) fs.bail = 2;
     __syncthreads();
 #ifdef BSSM_DEV_STAMPS
     if (t == 0) g.ws->stamps[1][MODE == MODE_W ? 9 : 14] = clock64();

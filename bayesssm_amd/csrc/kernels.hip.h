@@ -1501,6 +1501,9 @@ __device__ __forceinline__ void local_block(SegSmem& sm, uint64_t* tin /* [NT + 
 // Same scheme one level up: each thread owns CB consecutive block records; a
 // run of PURE blocks is a PURE chunk, anything else is a boundary chunk.
 // ---------------------------------------------------------------------------
+// literal-term counters: terms re-run from a side entry's own copy count as they are; a run that had to read the weights of a
+// block from HBM (literal_run) also adds LIT_FROM_W -- a fused launch, whose weights never reach HBM, must then stand down
+constexpr long long LIT_FROM_W = 1ll << 40;
 template <int MODE>
 __device__ __forceinline__ uint64_t block_out_exact_body(const BlockRec& br, const SideList* __restrict__ side, const double* __restrict__ w,
                                                          long long nw, double total, long long b, uint64_t in, long long& lit)
@@ -1509,7 +1512,7 @@ __device__ __forceinline__ uint64_t block_out_exact_body(const BlockRec& br, con
     uint64_t o = rec_step(br.prefix, in, ok);
     const long long e0 = b * EB, e1 = (e0 + EB < nw) ? e0 + EB : nw;
     if (!ok) {                                   // the prefix record does not cover this state: whole block literally
-        lit += (e1 > e0) ? e1 - e0 : 0;
+        lit += ((e1 > e0) ? e1 - e0 : 0) + LIT_FROM_W;
         return literal_run<MODE>(w, nw, total, e0, e1, in);
     }
     if (br.nside > 0) {
@@ -1530,7 +1533,7 @@ __device__ __forceinline__ uint64_t block_out_exact_body(const BlockRec& br, con
                 const int64_t diff = (int64_t)(o - e.post_base);
                 if (diff < (int64_t)e.lo || diff > (int64_t)e.hi) {
                     const long long j0 = e0 + (long long)(e.lane + 1) * EL;   // not covered: rest of the block literally
-                    if (j0 < e1) { lit += e1 - j0; o = literal_run<MODE>(w, nw, total, j0, e1, o); }
+                    if (j0 < e1) { lit += e1 - j0 + LIT_FROM_W; o = literal_run<MODE>(w, nw, total, j0, e1, o); }
                     return o;
                 }
                 Pure p; p.d0 = e.d0; p.d1 = e.d1;
@@ -1542,7 +1545,7 @@ __device__ __forceinline__ uint64_t block_out_exact_body(const BlockRec& br, con
     if (br.tail_from >= NT) return o;
     const long long j0 = e0 + (long long)br.tail_from * EL;
     if (j0 >= e1) return o;
-    lit += e1 - j0;
+    lit += e1 - j0 + LIT_FROM_W;
     return literal_run<MODE>(w, nw, total, j0, e1, o);
 }
 
@@ -1774,7 +1777,7 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
         }
         __syncthreads();
     }
-    if (lit && count_stats) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
+    if (lit && count_stats) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)(lit & (LIT_FROM_W - 1)));
     if (lit_out) *lit_out = lit;
     BSSM_STAMP(st, dbg, MODE, 7, stamper);
 #ifdef BSSM_DEV_STAMPS
@@ -1996,7 +1999,7 @@ __global__ __launch_bounds__(NTR) void k_resolve(const double* __restrict__ w, l
         }
         if (c1 == B) final_state = s;
     }
-    if (lit) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)lit);
+    if (lit) atomicAdd((unsigned long long*)&st->stat_literal_terms, (unsigned long long)(lit & (LIT_FROM_W - 1)));
     __syncthreads();
     BSSM_STAMP(st, dbg0, MODE, 7, t == 0);
     if (MODE == MODE_W) {

@@ -37,6 +37,10 @@ SWEEP_BYTES = 68.0
 SWEEP_READ_BYTES = 40.0
 # per-kernel algorithmic bytes per particle (this implementation's kernel split, d = 1)
 KERNEL_BYTES = {
+    # fused path: ONE launch is the whole observation, so SURVEY.md 8(d)'s per-unit figure applies to it as it stands (68 B per
+    # particle-step); the launch's own HBM traffic is 16 B per particle (x read, x written): log-weights, weights, cumulative sums
+    # and ancestors never leave the chip
+    "k_obs<systematic>": SWEEP_BYTES, "k_obs<stratified>": SWEEP_BYTES,
     "k_step<trans+weight>": 16.0,               # read x, write x'  (the log-weights are not stored: k_weights re-evaluates them)
     "k_weights(normalize+local<W>)": 16.0,      # read x' (-> log-weights), write w
     "k_local<W>": 8.0,                          # read w
@@ -61,8 +65,8 @@ REHEARSE = os.environ.get("BENCH_REHEARSE", "0") == "1"      # CPU rehearsal of 
 def kernel_source_hash():
     """sha256 over the kernel sources: PMC traffic figures are only quoted for the build they were collected on."""
     h = hashlib.sha256()
-    for rel in ("bayesssm_amd/csrc/kernels.hip.h", "bayesssm_amd/csrc/seqsum.h", "bayesssm_amd/csrc/rng.h",
-                "bayesssm_amd/csrc/bssm_api.hip"):
+    for rel in ("bayesssm_amd/csrc/kernels.hip.h", "bayesssm_amd/csrc/fused.hip.h", "bayesssm_amd/csrc/mv.hip.h", "bayesssm_amd/csrc/seqsum.h",
+                "bayesssm_amd/csrc/rng.h", "bayesssm_amd/csrc/bssm_api.hip"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -286,6 +290,10 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": kern[dom]["avg_us"]}
+            if dom.startswith("k_obs"):
+                out["roofline"]["note"] = ("one launch per observation (fused path): algorithmic bytes = SURVEY 8(d)'s 68 B per particle-step x N; "
+                                           "the launch itself moves 16 B per particle through HBM (particles in, particles out)")
+                out["roofline"]["own_hbm_bytes_per_launch"] = 16.0 * N
             if "+resolve" in dom:
                 out["roofline"]["note"] = ("this launch also contains the grid-level resolve of the pass before it, a separate "
                                            "single-workgroup launch until round 1 (k_resolve, 6.4-7.4 us): its duration is not "
