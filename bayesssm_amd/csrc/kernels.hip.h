@@ -2818,8 +2818,12 @@ __device__ __forceinline__ void step_emul(double* sh16, double* x, double* __res
     }
 }
 
-template <int MODEL, int ALG>      // ALG: 0 bootstrap, 1 auxiliary, 2 resample-move
-__global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : 2) void k_pf_batch(BatchArgs g)
+// ALG: 0 bootstrap, 1 auxiliary, 2 resample-move
+#ifndef BSSM_BATCH_WPE
+#define BSSM_BATCH_WPE 2
+#endif
+template <int MODEL, int ALG>
+__global__ __launch_bounds__(NT, (MODEL == 2 || ALG == 1) ? 1 : BSSM_BATCH_WPE) void k_pf_batch(BatchArgs g)
 {
     constexpr bool APF = (ALG == 1), RMPF = (ALG == 2);
     __shared__ SegSmem sm;
