@@ -129,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "bssm_ctx_set_profile", "bssm_ctx_get_profile", "bssm_ctx_set_option", "bssm_ctx_get_stamps", "bssm_pmmh_chain",
     "bssm_resample_multinomial_r",
     "bssm_pf_run_batch", "bssm_pf_batch_max_particles", "bssm_pmmh_chains_batch", "bssm_pmmh_chain_draws",
-    "bssm_pf_run_sharded", "bssm_pf_weigh_resample", "bssm_ctx_fused_stats", "bssm_ctx_fused_stamps", "bssm_dump_normals_mv",
+    "bssm_pf_run_sharded", "bssm_pf_weigh_resample", "bssm_ctx_fused_stats", "bssm_ctx_fused_stamps", "bssm_dump_normals_mv", "bssm_pf_run_multi", "bssm_pmmh_chains_multi",
 ]
 
 

@@ -16,6 +16,7 @@
 #include "kernels.hip.h"
 #include "fused.hip.h"
 #include "mv.hip.h"
+#include "multi.hip.h"
 #include <atomic>
 #include "../../include/bayesssm_amd.h"
 
@@ -183,6 +184,8 @@ extern "C" int bssm_ctx_create(int device, long long max_particles, int max_dim,
                             reinterpret_cast<const void*>(&k_apply<1, true, true>), reinterpret_cast<const void*>(&k_apply<1, false, true>)})
         if (e == hipSuccess) e = hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
     static_assert(sizeof(ResolveSmem) <= 3 * CAPX * sizeof(double), "the in-kernel resolve borrows k_apply's staging area");
+    for (const void* fnp : {reinterpret_cast<const void*>(&k_apply_multi<0>), reinterpret_cast<const void*>(&k_apply_multi<1>)})
+        if (e == hipSuccess) e = hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CAPX * (int)sizeof(double));
     if (e == hipSuccess) {
         // fused path: workspace (zeroed once: the tags only grow), dynamic LDS, and the residency it rests on -- two workgroups
         // per CU, every block of the largest grid resident at once
@@ -1091,6 +1094,190 @@ extern "C" int bssm_ctx_fused_stats(bssm_ctx* c, long long* out /* [4]: runs, la
     return BSSM_OK;
 }
 
+
+// ---- K independent large filters in lock-step on ONE stream (multi.hip.h) -------------------------------------------------
+// ctxs[k] holds filter k's buffers; every launch carries all K argument sets (blockIdx.y = filter).  Shared: data, N, T, model,
+// resampling settings; per filter: theta, seed, stream.  Each filter's outputs are bit-identical to bssm_pf_run's.  Configurations
+// outside the lock-step kernels' reach (APF / RMPF, SIR, multinomial, more than 2^20 particles, histories, injected draws) run
+// one after the other through bssm_pf_run.
+extern "C" int bssm_pf_run_multi(bssm_ctx* const* ctxs, int n_filters, const bssm_pf_config* cfg, const double* thetas,
+                                 const unsigned long long* seeds, const unsigned long long* streams, bssm_pf_batch_result* res)
+{
+    if (!ctxs || !cfg || !res || !thetas || !seeds || !streams) ARGFAIL("bssm_pf_run_multi: NULL argument");
+    const int F = n_filters;
+    if (F < 1 || F > MULTI_MAX) ARGFAIL("bssm_pf_run_multi: 1 .. 4 filters per call");
+    for (int k = 0; k < F; k++) { if (!ctxs[k]) ARGFAIL("bssm_pf_run_multi: NULL context"); for (int j = 0; j < k; j++) if (ctxs[j] == ctxs[k]) ARGFAIL("bssm_pf_run_multi: every filter needs a context of its own"); }
+    const long long N = cfg->num_particles;
+    const int T = cfg->T, nth = cfg->n_theta;
+    if (N <= 0) ARGFAIL("num_particles must be a positive count");
+    if (T < 0 || nth < 3) ARGFAIL("bssm_pf_run_multi: bad filter configuration");
+    if (!res->loglike) ARGFAIL("bssm_pf_run_multi: result buffers missing");
+    const int B = (int)((N + EB - 1) / EB);
+    bssm_ctx* c0 = ctxs[0];
+    bool lock = (cfg->model == BSSM_MODEL_LG || cfg->model == BSSM_MODEL_AR1SIN) && cfg->algorithm == BSSM_BPF && B <= 2 * NT &&
+                (cfg->resample_fn == BSSM_STRATIFIED || cfg->resample_fn == BSSM_SYSTEMATIC) && !cfg->return_particles && !cfg->return_ancestors &&
+                !cfg->z_init && !cfg->z_trans && !cfg->u_res && F > 1;
+    for (int k = 0; k < F && lock; k++) {
+        const bssm_ctx* c = ctxs[k];
+        lock = c->device == c0->device && N <= c->cap && c->opt_inkernel_resolve && c->opt_renormalize && c->opt_recompute_lw && !c->opt_fuse_step &&
+               !c->opt_debug_stop && c->opt_window == c0->opt_window && c->opt_stage == c0->opt_stage && !c->profile;
+    }
+    const int dim = 1;
+    if (!lock) {
+        // one after the other
+        double ms_total = 0;
+        int first_bad = BSSM_OK;
+        for (int k = 0; k < F; k++) {
+            bssm_pf_config q = *cfg;
+            q.theta = thetas + (size_t)k * nth; q.seed = seeds[k]; q.stream = streams[k];
+            const int d = (q.model == BSSM_MODEL_SIR) ? 2 : 1;
+            std::vector<double> se((size_t)(T + 1) * d), ess((size_t)T + 1), llh((size_t)std::max(T, 1));
+            double ll = 0, ms = 0; int early = 0, nres = 0;
+            bssm_pf_result r; memset(&r, 0, sizeof(r));
+            r.state_est = se.data(); r.ess = ess.data(); r.loglike_history = llh.data(); r.loglike = &ll; r.early_return_step = &early; r.n_res_calls = &nres; r.device_ms = &ms;
+            const int rc = bssm_pf_run(ctxs[k], &q, &r);
+            if (res->status) res->status[k] = rc;
+            if (rc && !first_bad) first_bad = rc;
+            res->loglike[k] = ll; ms_total += ms;
+            if (res->state_est) memcpy(res->state_est + (size_t)k * (T + 1) * d, se.data(), se.size() * 8);
+            if (res->ess) memcpy(res->ess + (size_t)k * (T + 1), ess.data(), ess.size() * 8);
+            if (res->loglike_history && T > 0) memcpy(res->loglike_history + (size_t)k * T, llh.data(), (size_t)T * 8);
+            if (res->early_return_step) res->early_return_step[k] = early;
+            if (res->n_res_calls) res->n_res_calls[k] = nres;
+        }
+        if (res->device_ms) *res->device_ms = ms_total;
+        return res->status ? BSSM_OK : first_bad;
+    }
+    for (int i = 0; i < T; i++) if (!isfinite(cfg->y[i])) ARGFAIL("Assertion on 'y' failed: Contains missing values");
+    if (cfg->obs_times) { int prev = 1; for (int i = 0; i < T; i++) { if (cfg->obs_times[i] < prev) ARGFAIL("Assertion on 'obs_times' failed: Must be sorted and >= 1"); prev = cfg->obs_times[i]; } }
+    HIPCHK(hipSetDevice(c0->device));
+    hipStream_t stream = c0->stream;
+    const double dN = (double)N;
+    const int resample_algorithm = cfg->resample_algorithm;
+    if (resample_algorithm < 0 || resample_algorithm > 2) ARGFAIL("bssm_pf_run_multi: unknown resample_algorithm");
+    double threshold = cfg->threshold;
+    if (isnan(threshold)) threshold = (resample_algorithm == BSSM_SIS) ? INFINITY : (resample_algorithm == BSSM_SISR) ? dN : dN / 2;
+    const int lim = c0->opt_window > 0 ? c0->opt_window : rec_window(N);
+    const size_t n_gmax = (size_t)T + 2, gm_words = (size_t)GM_SLOTS * GM_STRIDE;
+    struct Per { void *d_ess, *d_llh, *d_se, *d_separt, *d_resampled, *d_gmax; ModelPar par; PhiloxKey key; double *X0, *X1; };
+    std::vector<Per> P((size_t)F);
+    for (int k = 0; k < F; k++) {
+        bssm_ctx* c = ctxs[k];
+        HIPCHK(hipStreamSynchronize(c->stream));                     // (its buffers may still be in use by its own stream)
+        int rc;
+        if ((rc = pool_get(c, "ess", (size_t)(T + 1) * 8, &P[k].d_ess))) return rc;
+        if ((rc = pool_get(c, "llh", (size_t)(T + 1) * 8, &P[k].d_llh))) return rc;
+        if ((rc = pool_get(c, "se", (size_t)(T + 1) * dim * 8, &P[k].d_se))) return rc;
+        if ((rc = pool_get(c, "separt", (size_t)(T + 1) * B * dim * 8, &P[k].d_separt))) return rc;
+        if ((rc = pool_get(c, "resampled", (size_t)(T + 1) * 4, &P[k].d_resampled))) return rc;
+        if ((rc = pool_get(c, "gmax", n_gmax * gm_words * 8, &P[k].d_gmax))) return rc;
+        HIPCHK(hipMemsetAsync(P[k].d_gmax, 0, n_gmax * gm_words * 8, stream));
+        HIPCHK(hipMemsetAsync(P[k].d_separt, 0, (size_t)(T + 1) * B * dim * 8, stream));
+        HIPCHK(hipMemsetAsync(P[k].d_ess, 0, (size_t)(T + 1) * 8, stream));
+        HIPCHK(hipMemsetAsync(P[k].d_llh, 0, (size_t)(T + 1) * 8, stream));
+        HIPCHK(hipMemsetAsync(P[k].d_resampled, 0, (size_t)(T + 1) * 4, stream));
+        const double* th = thetas + (size_t)k * nth;
+        memset(&P[k].par, 0, sizeof(ModelPar));
+        P[k].par.phi = th[0]; P[k].par.sx = th[1]; P[k].par.sy = th[2]; P[k].par.log_sy = log(th[2]);
+        P[k].key = make_key(seeds[k], streams[k]);
+        P[k].X0 = c->x0; P[k].X1 = c->x1;
+    }
+    HIPCHK(hipEventRecord(c0->ev0, stream));
+    for (int k = 0; k < F; k++) {
+        hipLaunchKernelGGL(k_reset_state, dim3(1), dim3(1), 0, stream, ctxs[k]->st);
+        NoiseSrc ns; ns.arr = nullptr; ns.key = P[k].key; ns.purpose = DRAW_INIT; ns.call = 0;
+        hipLaunchKernelGGL(k_init, dim3(B), dim3(NT), 0, stream, P[k].X0, N, ns, (double*)P[k].d_separt, cfg->model, P[k].par, 0);
+    }
+    const bool sysk = cfg->resample_fn == BSSM_SYSTEMATIC;
+    const long long u_stride = sysk ? 1 : N;
+    int ktrans = 0, prev_t = 0;
+    size_t wcall = 0;
+    for (int i = 1; i <= T; i++) {                                                        // R/particle_filter_core.R:123
+        const int ot = cfg->obs_times ? cfg->obs_times[i - 1] : i;
+        const int gap = ot - prev_t;
+        prev_t = ot;
+        const double yi = cfg->y[i - 1];
+        const size_t gslot = (wcall < n_gmax ? wcall : n_gmax - 1) * gm_words; wcall++;
+        StepMulti sm; LocalMulti lw_, lp_; ApplyMulti am;
+        for (int step = 1; step <= std::max(gap, 1); step++) {
+            const bool last = (step >= gap), trans = gap >= 1;
+            for (int k = 0; k < F; k++) {
+                StepArgs& a = sm.a[k];
+                a.xin = P[k].X0; a.xout = P[k].X0; a.lw = nullptr; a.N = N; a.par = P[k].par; a.y = yi;
+                a.ns.arr = nullptr; a.ns.key = P[k].key; a.ns.purpose = DRAW_TRANS; a.ns.call = (uint32_t)ktrans;
+                a.pm = ctxs[k]->pm; a.ps = ctxs[k]->ps; a.pq = ctxs[k]->pq; a.st = ctxs[k]->st; a.gmax = (unsigned long long*)P[k].d_gmax + gslot;
+            }
+            const dim3 grid(B, F);
+            if (cfg->model == BSSM_MODEL_LG) {
+                if (trans && last) hipLaunchKernelGGL((k_step_multi<0, true, 1>), grid, dim3(NTS), 0, stream, sm);
+                else if (trans) hipLaunchKernelGGL((k_step_multi<0, true, 0>), grid, dim3(NTS), 0, stream, sm);
+                else hipLaunchKernelGGL((k_step_multi<0, false, 1>), grid, dim3(NTS), 0, stream, sm);
+            } else {
+                if (trans && last) hipLaunchKernelGGL((k_step_multi<1, true, 1>), grid, dim3(NTS), 0, stream, sm);
+                else if (trans) hipLaunchKernelGGL((k_step_multi<1, true, 0>), grid, dim3(NTS), 0, stream, sm);
+                else hipLaunchKernelGGL((k_step_multi<1, false, 1>), grid, dim3(NTS), 0, stream, sm);
+            }
+            if (trans) ktrans++;
+        }
+        for (int k = 0; k < F; k++) {
+            bssm_ctx* c = ctxs[k];
+            FromLw f; f.lw = c->lw; f.xw = P[k].X0; f.yw = yi; f.syw = P[k].par.sy; f.lsyw = P[k].par.log_sy; f.w_out = c->w; f.pm = c->pm; f.ps = c->ps; f.pq = c->pq; f.nb = B;
+            f.lead = 0; f.pub = B / 2; f.fold = 0; f.gmax = (unsigned long long*)P[k].d_gmax + gslot; f.ain_out = c->ain_w; f.plan = PLAN_PF; f.N = N; f.obs_i = i;
+            f.resample_algorithm = resample_algorithm; f.threshold = threshold; f.ess_out = (double*)P[k].d_ess; f.llh_out = (double*)P[k].d_llh; f.resampled_out = (int*)P[k].d_resampled;
+            LocalArgs& w_ = lw_.a[k];
+            w_.w = c->w; w_.nw = N; w_.ain = c->ain_w; w_.lim = lim; w_.brec = c->brec; w_.side = c->side; w_.st = c->st; w_.f = f; w_.prev_brec = nullptr; w_.prev_side = nullptr; w_.ain_p_out = nullptr;
+            LocalArgs& p_ = lp_.a[k];
+            p_ = w_; p_.brec = c->brec_p; p_.side = c->side_p; p_.prev_brec = c->brec; p_.prev_side = c->side; p_.ain_p_out = c->ain_p;
+            ApplyOne& q = am.a[k];
+            ApplyArgs& a = q.a;
+            a.w = c->w; a.nw = N; a.ain_p = c->ain_p; a.cin = c->cin; a.lim = lim; a.n = (int)N; a.u_base = nullptr; a.u_stride = u_stride; a.key = P[k].key;
+            a.anc_out = nullptr; a.anc_stride = 0; a.cum_out = nullptr; a.xsrc = P[k].X0; a.xdst = P[k].X1; a.dim = 1; a.xstride = N; a.auxsrc = nullptr; a.auxdst = nullptr;
+            a.se_part = (double*)P[k].d_separt + (size_t)i * B * dim; a.nstage = c0->opt_stage ? 1 : 0; a.lead = 0; a.last = B - 1;
+            a.step_model = -1; a.step_par = P[k].par; a.step_y = 0; a.step_ns.arr = nullptr; a.step_ns.key = P[k].key; a.step_ns.purpose = 0; a.step_ns.call = 0; a.step_lw = nullptr;
+            q.st = c->st; q.prev_brec = c->brec_p; q.prev_side = c->side_p;
+        }
+        const dim3 g2(B, F);
+        hipLaunchKernelGGL(k_weights_multi, g2, dim3(NT), 0, stream, lw_);
+        hipLaunchKernelGGL(k_localp_multi, g2, dim3(NT), 0, stream, lp_);
+        const size_t xshm = std::max((size_t)(c0->opt_stage ? 1 : 0) * CAPX * sizeof(double), sizeof(ResolveSmem));
+        if (sysk) hipLaunchKernelGGL((k_apply_multi<1>), g2, dim3(NT), xshm, stream, am);
+        else hipLaunchKernelGGL((k_apply_multi<0>), g2, dim3(NT), xshm, stream, am);
+        for (int k = 0; k < F; k++) {
+            if (resample_algorithm != BSSM_SISR)
+                hipLaunchKernelGGL(k_carry, dim3(B), dim3(NT), 0, stream, P[k].X0, P[k].X1, ctxs[k]->w, N, dim, (double*)P[k].d_separt + (size_t)i * B * dim, ctxs[k]->st, 0);
+            std::swap(P[k].X0, P[k].X1);
+        }
+    }
+    for (int k = 0; k < F; k++)
+        hipLaunchKernelGGL(k_reduce_state_est, dim3(T + 1), dim3(NT), 0, stream, (double*)P[k].d_separt, B, dim, (double*)P[k].d_se);
+    HIPCHK(hipEventRecord(c0->ev1, stream));
+    HIPCHK(hipGetLastError());
+    std::vector<DevState> hs((size_t)F);
+    std::vector<double> se((size_t)(T + 1)), ess((size_t)T + 1), llh((size_t)std::max(T, 1));
+    HIPCHK(hipStreamSynchronize(stream));
+    int first_bad = BSSM_OK;
+    for (int k = 0; k < F; k++) {
+        HIPCHK(hipMemcpy(&hs[k], ctxs[k]->st, sizeof(DevState), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(se.data(), P[k].d_se, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ess.data(), P[k].d_ess, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost));
+        if (T > 0) HIPCHK(hipMemcpy(llh.data(), P[k].d_llh, (size_t)T * 8, hipMemcpyDeviceToHost));
+        const DevState& h = hs[k];
+        ess[0] = 1.0 / (dN * ((1.0 / dN) * (1.0 / dN)));
+        if (h.dead) { for (int i = h.dead; i <= T; i++) { ess[i] = 0.0; se[i] = 0.0; } for (int i = h.dead; i < T; i++) llh[i] = 0.0; }
+        res->loglike[k] = h.loglike;
+        if (res->state_est) memcpy(res->state_est + (size_t)k * (T + 1), se.data(), (size_t)(T + 1) * 8);
+        if (res->ess) memcpy(res->ess + (size_t)k * (T + 1), ess.data(), (size_t)(T + 1) * 8);
+        if (res->loglike_history && T > 0) memcpy(res->loglike_history + (size_t)k * T, llh.data(), (size_t)T * 8);
+        if (res->early_return_step) res->early_return_step[k] = h.dead;
+        if (res->n_res_calls) res->n_res_calls[k] = h.res_calls;
+        const int stf = h.flags ? flags_to_status(h.flags) : BSSM_OK;
+        if (res->status) res->status[k] = stf;
+        if (stf && !first_bad) { first_bad = stf; if (stf != BSSM_ERR_ARG) g_err = bssm_status_string(stf); }
+    }
+    if (res->device_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c0->ev0, c0->ev1)); *res->device_ms = ms; }
+    return res->status ? BSSM_OK : first_bad;
+}
+
 // ---- closure mode: normalise, decide, resample for host-evaluated log-weights -------------------------------------
 extern "C" int bssm_pf_weigh_resample(bssm_ctx* c, long long n, const double* lw, int always, int resample_algorithm,
                                       double threshold, int resample_fn, const double* U, unsigned long long seed,
@@ -1761,6 +1948,63 @@ extern "C" int bssm_pmmh_chains_batch(bssm_ctx* c, int n_chains, const bssm_pmmh
         }
         if (F == 0) continue;
         const int rc = bssm_pf_run_batch(c, &pf, F, thetas.data(), seeds.data(), streams.data(), &br);
+        if (rc) return rc;
+        ms_total += ms;
+        for (int f = 0; f < F; f++) {
+            ChainState& s = ch[who[f]];
+            std::vector<double>& dst = (i == 0) ? s.se_cur : s.se_prop;
+            memcpy(dst.data(), se.data() + (size_t)f * (T + 1) * dim, sizeof(double) * (T + 1) * dim);
+            if (i == 0) s.start(ll[f]); else s.finish(i, ll[f]);
+        }
+    }
+    for (int k = 0; k < n_chains; k++) {
+        if (ress[k].accepted) *ress[k].accepted = ch[k].accepted;
+        if (ress[k].device_ms) *ress[k].device_ms = ms_total / n_chains;
+    }
+    return BSSM_OK;
+}
+
+// The same lock-step loop for LARGE filters: iteration i of every chain proposes on the host, ONE run of bssm_pf_run_multi (the kernels of
+// bssm_pf_run, one argument set per chain) filters all the proposals, every chain accepts or rejects (R/pmmh.R:422-500).  ctxs: one context per
+// chain (at most 4).  Chain draws are keyed by (seed, chain index) and the filters are bit-identical to bssm_pf_run, so each chain equals
+// bssm_pmmh_chain's.
+extern "C" int bssm_pmmh_chains_multi(bssm_ctx* const* ctxs, int n_chains, const bssm_pmmh_config* cfgs, bssm_pmmh_result* ress)
+{
+    if (!ctxs || !cfgs || !ress) ARGFAIL("bssm_pmmh_chains_multi: NULL argument");
+    if (n_chains < 1 || n_chains > MULTI_MAX) ARGFAIL("bssm_pmmh_chains_multi: 1 .. 4 chains per call");
+    std::vector<ChainState> ch((size_t)n_chains);
+    for (int k = 0; k < n_chains; k++) { const int rc = ch[k].init(&cfgs[k], &ress[k]); if (rc) return rc; }
+    const bssm_pf_config& pf0 = cfgs[0].pf;
+    const int T = ch[0].T, m = ch[0].m, nth = ch[0].n_full;
+    for (int k = 1; k < n_chains; k++) {
+        const bssm_pf_config& q = cfgs[k].pf;
+        if (ch[k].m != m || ch[k].T != T || ch[k].n_full != nth || q.model != pf0.model || q.algorithm != pf0.algorithm ||
+            q.num_particles != pf0.num_particles || q.resample_algorithm != pf0.resample_algorithm || q.resample_fn != pf0.resample_fn ||
+            !(q.threshold == pf0.threshold || (isnan(q.threshold) && isnan(pf0.threshold))) || q.y != pf0.y || q.obs_times != pf0.obs_times)
+            ARGFAIL("bssm_pmmh_chains_multi: the chains must share the data, the filter settings and m");
+    }
+    bssm_pf_config pf = pf0;
+    pf.n_theta = nth; pf.theta = nullptr; pf.return_particles = 0; pf.return_ancestors = 0; pf.z_init = pf.z_trans = pf.u_res = nullptr;
+    const int dim = ch[0].dim;
+    std::vector<double> thetas((size_t)n_chains * nth), ll((size_t)n_chains), se((size_t)n_chains * (T + 1) * dim);
+    std::vector<unsigned long long> seeds((size_t)n_chains), streams((size_t)n_chains);
+    std::vector<int> who((size_t)n_chains);
+    double ms = 0, ms_total = 0;
+    bssm_pf_batch_result br; memset(&br, 0, sizeof(br));
+    br.loglike = ll.data(); br.state_est = se.data(); br.device_ms = &ms;
+    for (int i = 0; i < m; i++) {
+        int F = 0;
+        for (int k = 0; k < n_chains; k++) {
+            const bool run = (i == 0) ? true : ch[k].propose(i);
+            if (!run) continue;
+            const double* th = ch[k].full_theta(i == 0 ? ch[k].cur : ch[k].prop);
+            for (int j = 0; j < nth; j++) thetas[(size_t)F * nth + j] = th[j];
+            seeds[F] = cfgs[k].seed; streams[F] = ch[k].stream_of((unsigned)i); who[F] = k; F++;
+        }
+        if (F == 0) continue;
+        std::vector<bssm_ctx*> cx((size_t)F);
+        for (int f = 0; f < F; f++) cx[f] = ctxs[who[f]];
+        const int rc = bssm_pf_run_multi(cx.data(), F, &pf, thetas.data(), seeds.data(), streams.data(), &br);
         if (rc) return rc;
         ms_total += ms;
         for (int f = 0; f < F; f++) {

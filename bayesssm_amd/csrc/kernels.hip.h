@@ -432,17 +432,15 @@ constexpr int NTS = 1024;        // threads per workgroup of k_step: one particl
                                  // (the transcendental chains need the occupancy to hide their latency)
 
 template <int MODEL, bool TRANS, int WEIGHT, bool SUBAUX>
-__global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /* may alias xin */,
-                                              double* __restrict__ lw, const double* __restrict__ auxg,
-                                              long long N, ModelPar par, double y, NoiseSrc ns,
-                                              double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq,
-                                              const DevState* __restrict__ st, unsigned long long* __restrict__ gmax, int boff)
+__device__ __forceinline__ void step_block(double* sh /* [2 NTS / 64] */, const int bx, const double* xin, double* xout /* may alias xin */,
+                                           double* __restrict__ lw, const double* __restrict__ auxg,
+                                           long long N, const ModelPar& par, double y, const NoiseSrc& ns,
+                                           double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq,
+                                           const DevState* __restrict__ st, unsigned long long* __restrict__ gmax)
 {
-    const int bx = (int)blockIdx.x + boff;
     // (no early return on st->dead here: a dependent read of the run state in front of the particle loads would
     //  cost every launch a memory round trip; propagating a dead run is harmless, its results are never read)
     (void)st;
-    __shared__ double sh[2 * (NTS / 64)];
     const long long j = (long long)bx * EB + 2 * (long long)threadIdx.x;
     double l0 = -INFINITY, l1 = -INFINITY;
     if (j < N) {
@@ -485,6 +483,17 @@ __global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /*
         // it with one load instead of reducing the B block maxima again in every workgroup
         if (threadIdx.x == 0) { pm[bx] = bm; ps[bx] = s; pq[bx] = q; if (gmax) atomicMax(gmax + (bx % GM_SLOTS) * GM_STRIDE, f64_key(bm)); }
     }
+}
+
+template <int MODEL, bool TRANS, int WEIGHT, bool SUBAUX>
+__global__ __launch_bounds__(NTS) void k_step(const double* xin, double* xout /* may alias xin */,
+                                              double* __restrict__ lw, const double* __restrict__ auxg,
+                                              long long N, ModelPar par, double y, NoiseSrc ns,
+                                              double* __restrict__ pm, double* __restrict__ ps, double* __restrict__ pq,
+                                              const DevState* __restrict__ st, unsigned long long* __restrict__ gmax, int boff)
+{
+    __shared__ double sh[2 * (NTS / 64)];
+    step_block<MODEL, TRANS, WEIGHT, SUBAUX>(sh, (int)blockIdx.x + boff, xin, xout, lw, auxg, N, par, y, ns, pm, ps, pq, st, gmax);
 }
 
 // k_lw_partials: the per-block (max, sum exp, sum exp^2) partials of k_step for log-weights that are ALREADY in HBM --

@@ -194,6 +194,50 @@ def bootstrap_filter_batch(y, num_particles, init_fn, transition_fn, log_likelih
             "n_res_calls": nres, "status": status, "device_ms": float(ms[0]), "algorithm": _algorithm}
 
 
+def bootstrap_filter_multi(y, num_particles, init_fn, transition_fn, log_likelihood_fn, thetas, seeds=0, streams=None, obs_times=None,
+                           resample_algorithm=None, resample_fn=None, threshold=None, ctxs=None):
+    """K (<= 4) independent LARGE bootstrap filters in lock-step on one stream (bssm_pf_run_multi): the launches of one filter run
+    carry all K filters (blockIdx.y), so independent PMMH chains (R/pmmh.R:511-531) share them.  Filter k runs with thetas[k],
+    seeds[k], streams[k] on the shared data and returns exactly what bootstrap_filter(..., seed=seeds[k], stream=streams[k],
+    return_particles=False) returns.  ctxs: one Context per filter (created and closed here when None).
+    Returns a dict of arrays like bootstrap_filter_batch."""
+    resample_algorithm = _match_arg(resample_algorithm, _RESAMPLE_ALGORITHMS, "resample_algorithm")
+    resample_fn = _match_arg(resample_fn, _RESAMPLE_FNS, "resample_fn")
+    model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    if y.ndim != 1 or not np.all(np.isfinite(y)):
+        raise ValueError("Assertion on 'y' failed")
+    T, N = int(y.size), int(num_particles)
+    ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
+    thetas = np.ascontiguousarray(thetas, dtype=np.float64)
+    F = int(thetas.shape[0])
+    if not 1 <= F <= 4:
+        raise ValueError("bootstrap_filter_multi: 1 .. 4 filters per call")
+    seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (F,)))
+    streams = np.arange(F, dtype=np.uint64) if streams is None else np.ascontiguousarray(np.broadcast_to(np.asarray(streams, dtype=np.uint64), (F,)))
+    dim = models.dim_of(model)
+    own = ctxs is None
+    if own:
+        ctxs = [_lib.Context(_lib.default_context(1).device, N, dim) for _ in range(F)]
+    try:
+        ll, se, ess = np.zeros(F), (np.zeros((F, T + 1, dim)) if dim > 1 else np.zeros((F, T + 1))), np.zeros((F, T + 1))
+        llh, ers, nres, status, ms = np.zeros((F, max(T, 1))), np.zeros(F, dtype=np.int32), np.zeros(F, dtype=np.int32), np.zeros(F, dtype=np.int32), np.zeros(1)
+        cfg = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM["BPF"], _lib.RESAMPLE_ALGORITHM[resample_algorithm], _lib.RESAMPLE_FN[resample_fn],
+                            N, T, float("nan") if threshold is None else float(threshold), None, int(thetas.shape[1]), _ptr(y), _ptr(ot), 0, 0,
+                            None, None, None, 0, 0, 0.0, None, None)
+        res = _lib.PfBatchResult(_ptr(ll), _ptr(se), _ptr(ess), _ptr(llh), _ptr(ers), _ptr(nres), _ptr(status), _ptr(ms))
+        handles = (C.c_void_p * F)(*[cx.handle for cx in ctxs[:F]])
+        lib = _lib.load()
+        lib.bssm_pf_run_multi.argtypes = [C.c_void_p, C.c_int, C.POINTER(_lib.PfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_lib.PfBatchResult)]
+        _lib.check(lib.bssm_pf_run_multi(handles, F, C.byref(cfg), _ptr(thetas), _ptr(seeds), _ptr(streams), C.byref(res)))
+    finally:
+        if own:
+            for cx in ctxs:
+                cx.close()
+    return {"loglike": ll, "state_est": se, "ess": ess, "loglike_history": llh[:, :T], "early_return_step": ers, "n_res_calls": nres,
+            "status": status, "device_ms": float(ms[0])}
+
+
 def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn, obs_times=None,
                      resample_algorithm=None, resample_fn=None, threshold=None, return_particles=True, **kwargs):
     """bootstrap_filter (R/bootstrap_filter.R:129-171).  Model parameters are passed by name

@@ -355,6 +355,51 @@ def run_chains_batch_device(pf_wrapper, y, m, model, n_params, init_thetas, prop
     return outs
 
 
+def multi_eligible(pf_wrapper, model, num_particles, resample_fn):
+    """Can this filter configuration run K chains' filters in lock-step launches (bssm_pf_run_multi)?"""
+    from .filters import bootstrap_filter
+    return (pf_wrapper is bootstrap_filter and model in ("lg", "ar1sin") and resample_fn in ("stratified", "systematic")
+            and int(num_particles) <= (1 << 20))
+
+
+def run_chains_multi_device(y, m, model, n_params, init_thetas, proposal_covs, transform, priors, num_particles, seeds, chain_indices,
+                            ctxs, obs_times=None, resample_algorithm="SISAR", resample_fn="stratified", return_latent_state_est=False):
+    """Up to 4 chains of LARGE filters in lock-step (bssm_pmmh_chains_multi): iteration i of every chain is one filter run whose
+    launches carry all the chains' proposals.  Chain k's result equals run_chain_device(...) with the k-th start, covariance, seed
+    and chain index -- bit for bit.  ctxs: one Context per chain."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    T, K = y.size, len(chain_indices)
+    ot = np.ascontiguousarray(obs_times, dtype=np.int32) if obs_times is not None else None
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None   # noqa: E731
+    tr = np.ascontiguousarray([_lib.TRANSFORM[t] for t in transform], dtype=np.int32)
+    pk = np.ascontiguousarray([_lib.PRIOR[p.kind] for p in priors], dtype=np.int32)
+    pa = np.ascontiguousarray([p.a for p in priors], dtype=np.float64)
+    pb = np.ascontiguousarray([p.b for p in priors], dtype=np.float64)
+    keep, cfgs, ress, outs = [], [], [], []
+    for k in range(K):
+        init_theta = np.ascontiguousarray(init_thetas[k], dtype=np.float64)
+        cov = np.ascontiguousarray(proposal_covs[k], dtype=np.float64).reshape(n_params, n_params)
+        pf = _lib.PfConfig(_lib.MODEL[model], _lib.ALGORITHM["BPF"], _lib.RESAMPLE_ALGORITHM[resample_algorithm], _lib.RESAMPLE_FN[resample_fn],
+                           int(num_particles), int(T), float("nan"), ptr(init_theta), int(init_theta.size), ptr(y), ptr(ot), int(seeds[k]), 0,
+                           None, None, None, 0, 0)
+        cfgs.append(_lib.PmmhConfig(pf, int(m), int(n_params), ptr(init_theta), ptr(cov), ptr(tr), ptr(pk), ptr(pa), ptr(pb), int(seeds[k]),
+                                    int(chain_indices[k]), 1 if return_latent_state_est else 0, None, None))
+        theta_chain, ll_chain = np.zeros((m, n_params)), np.zeros(m)
+        se_chain = np.zeros((m, T + 1)) if return_latent_state_est else None
+        acc, ms = np.zeros(1, dtype=np.int32), np.zeros(1)
+        ress.append(_lib.PmmhResult(ptr(theta_chain), ptr(ll_chain), ptr(se_chain), ptr(acc), ptr(ms)))
+        keep.append((init_theta, cov))
+        outs.append({"theta_chain": theta_chain, "loglike_chain": ll_chain, "state_est_chain": se_chain, "_acc": acc, "_ms": ms})
+    carr, rarr = (_lib.PmmhConfig * K)(*cfgs), (_lib.PmmhResult * K)(*ress)
+    handles = (C.c_void_p * K)(*[cx.handle for cx in ctxs[:K]])
+    lib = _lib.load()
+    lib.bssm_pmmh_chains_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _lib.check(lib.bssm_pmmh_chains_multi(handles, K, C.cast(carr, C.c_void_p), C.cast(rarr, C.c_void_p)))
+    for o in outs:
+        o["accepted"] = int(o.pop("_acc")[0]); o["device_ms"] = float(o.pop("_ms")[0]); o["lockstep_launches"] = True
+    return outs
+
+
 def _mvrnorm(mu, sigma, z):
     """MASS::mvrnorm(1, mu, Sigma) on p standard normals z (R/pmmh.R:425-428): mu + V diag(sqrt(pmax(ev, 0))) z with
     eigen(Sigma, symmetric = TRUE) (eigenvalues decreasing, each eigenvector's largest component positive)."""
@@ -691,6 +736,7 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     # filter leaves most of the chip idle between its dependent launches (measured on C2's filter, particle-steps/s on one
     # GPU: 19 G with one run in flight, 29 G with two, 32-34 G with four).
     conc = int(kwargs.pop("chains_per_gpu", 4 if _chain_runner is None else 1))
+    lockstep_large = bool(kwargs.pop("lockstep_large", False))
     conc = max(1, min(conc, len(mine)))
     ctxs = []
     if conc > 1:
@@ -777,6 +823,24 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
             for c, o in zip(cs, outs):
                 results[c] = o
         rest = groups.get(None, [])
+        # Filters above the batched kernel's size: `lockstep_large` = chains of one rank advance in lock-step, the launches of ONE filter run
+        # carrying up to 4 chains' proposals (bssm_pmmh_chains_multi); otherwise up to `chains_per_gpu` chains on separate streams
+        if lockstep_large and _chain_runner is None and len(rest) > 1 and ctxs and not (owner is not None and owner.constants):
+            by_n = {}
+            for c in rest:
+                if multi_eligible(pf_wrapper, model, preps[c]["n"], pf_rf):
+                    by_n.setdefault(preps[c]["n"], []).append(c)
+            for n_g, cs in by_n.items():
+                for g0 in range(0, len(cs), min(4, len(ctxs))):
+                    grp = cs[g0:g0 + min(4, len(ctxs))]
+                    if len(grp) < 2:
+                        continue
+                    outs = run_chains_multi_device(y, m, model, n_params, [preps[c]["init_theta"] for c in grp], [preps[c]["cov"] for c in grp],
+                                                   transform, priors, n_g, [int(seeds[c]) for c in grp], grp, ctxs, obs_times, pf_ra, pf_rf,
+                                                   return_latent_state_est)
+                    for c, o in zip(grp, outs):
+                        results[c] = o
+            rest = [c for c in rest if c not in results]
         results.update(run_pool(lambda c, cx: main_chain(c, preps[c], cx), rest))
         for c in mine:
             if preps[c]["pilot"] is not None:

@@ -424,6 +424,24 @@ def main():
                                                      "pmmh_iters_per_sec": 2 * K / dt4}
             inflight["note"] = "K host threads x K contexts (HIP streams), 2 filter runs each, same C2 workload on ONE GPU"
             out["runs_in_flight"] = inflight
+            # the same question answered with ONE launch stream: K filters per launch (blockIdx.y = filter; bssm_pf_run_multi), each filter
+            # bit-identical to a run of its own (tests/test_gpu_multi.py).  Measured slower than K streams: streams overlap DIFFERENT kernels of
+            # different runs (a VALU-bound k_step beside a latency-bound k_apply), lock-step launches only put like beside like, and the
+            # expansion kernel (198 VGPRs with its in-kernel resolve) is resident two workgroups per CU either way.
+            lock = {}
+            for K in (2, 4):
+                cxs = [ctx] + [b.Context(0, N, 1) for _ in range(K - 1)]
+                th = np.tile(theta, (K, 1))
+                mk = dict(resample_algorithm="SISR", resample_fn=args.resample_fn, ctxs=cxs)
+                b.bootstrap_filter_multi(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, th, 1405, list(range(7000, 7000 + K)), **mk)
+                t5_ = time.perf_counter()
+                b.bootstrap_filter_multi(ys, N, m.init_fn, m.transition_fn, m.log_likelihood_fn, th, 1405, list(range(7100, 7100 + K)), **mk)
+                dt5 = time.perf_counter() - t5_
+                for cx in cxs[1:]:
+                    cx.close()
+                lock["filters_per_launch=%d" % K] = {"particle_steps_per_s": K * float(N) * T / dt5, "pmmh_iters_per_sec": K / dt5}
+            lock["note"] = "ONE launch stream, K filters per launch (lock-step); compare runs_in_flight (K streams)"
+            out["filters_per_launch"] = lock
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ys, theta, N)
     if dist is not None:

@@ -264,6 +264,15 @@ int bssm_pf_batch_max_particles(void);
 int bssm_pf_run_batch(bssm_ctx* ctx, const bssm_pf_config* cfg, int n_filters, const double* thetas /* [n_filters][cfg->n_theta] */,
                       const unsigned long long* seeds, const unsigned long long* streams, bssm_pf_batch_result* res);
 
+/* K (<= 4) independent LARGE filters in lock-step on one stream: the kernels of bssm_pf_run with one argument set per filter
+ * (blockIdx.y), so that independent PMMH chains (R/pmmh.R:511-531) share the launches of their filter runs (R/pmmh.R:445-457)
+ * instead of each walking its own chain of latency-bound launches.  ctxs[k] owns filter k's buffers (same device); cfg holds the
+ * shared data and settings (theta / seed / stream / injected draws / histories unused), thetas [n_filters][cfg->n_theta].  Each
+ * filter's outputs are bit-identical to bssm_pf_run with that theta, seed and stream.  Configurations the lock-step kernels do
+ * not cover (APF / RMPF, SIR, multinomial, N > 2^20) run one after the other through bssm_pf_run. */
+int bssm_pf_run_multi(bssm_ctx* const* ctxs, int n_filters, const bssm_pf_config* cfg, const double* thetas,
+                      const unsigned long long* seeds, const unsigned long long* streams, bssm_pf_batch_result* res);
+
 /* Number of transition_fn / resample calls the filter makes at most (sizes of
  * the injected-draw arrays and of `ancestors`). */
 int bssm_pf_noise_shape(int algorithm, int T, const int* obs_times, int* max_trans, int* max_res);
@@ -323,6 +332,8 @@ int bssm_pmmh_chain_draws(unsigned long long seed, int chain_index, int m, int n
  * (N <= 2048).  ress[k] is exactly what bssm_pmmh_chain returns for
  * cfgs[k]; device_ms reports the total device time divided by n_chains. */
 int bssm_pmmh_chains_batch(bssm_ctx* ctx, int n_chains, const bssm_pmmh_config* cfgs, bssm_pmmh_result* ress);
+/* The lock-step loop over bssm_pf_run_multi for filters above the batched kernel's size: one context per chain, at most 4 chains. */
+int bssm_pmmh_chains_multi(bssm_ctx* const* ctxs, int n_chains, const bssm_pmmh_config* cfgs, bssm_pmmh_result* results);
 
 #ifdef __cplusplus
 }
