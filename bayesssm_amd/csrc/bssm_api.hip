@@ -1080,6 +1080,13 @@ extern "C" int bssm_ctx_fused_stamps(bssm_ctx* c, long long* out /* [2][24] */)
     return BSSM_OK;
 }
 
+extern "C" int bssm_ctx_fused_endt(bssm_ctx* c, long long* out /* [512] */)
+{
+    if (!c || !out || !c->fz) ARGFAIL("bssm_ctx_fused_endt: NULL argument");
+    HIPCHK(hipMemcpy(out, c->fz->endt, sizeof(c->fz->endt), hipMemcpyDeviceToHost));
+    return BSSM_OK;
+}
+
 extern "C" int bssm_ctx_fused_pubt(bssm_ctx* c, long long* out /* [4][512] */)
 {
     if (!c || !out || !c->fz) ARGFAIL("bssm_ctx_fused_pubt: NULL argument");

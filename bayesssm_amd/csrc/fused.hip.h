@@ -57,6 +57,7 @@ struct FusedWs {
     BlockRec brec_priv[2][MAXB];                 // (four planes each, BREC_STRIDE apart)
     SideList side_priv[2][FZ_MAXB];
     long long stamps[2][24];
+    long long endt[FZ_MAXB];                     // dev tool: wall clock at the end of every block's expansion
     long long pubt[4][FZ_MAXB];                  // dev tool: wall clock (100 MHz) of every block's three publishes; [3][8..10] resolver's gather-done times                     // dev tool (make DEV=1): clock64() at the stages of a typical worker [0] / of the resolver [1], last launch
 };
 
@@ -683,6 +684,11 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
     __syncthreads();
     apply_tail<KIND, false, CAPX, false>(sm, Tl, Tbegin, bidx, B, g.a, st, g.a.nstage ? lx + EB : nullptr, g.a.nstage, v, ent, xs0, xs1, axs, call, us, Usys, 0, false, lx);
     FZ_STAMP(18);
+#ifdef BSSM_DEV_STAMPS
+    if (t == 0) g.ws->pubt[3][32 + (bidx & 255)] = 0;      // (keeps the array referenced)
+    __syncthreads();
+    if (t == 0) g.ws->endt[bidx] = (long long)wall_clock64();
+#endif
 }
 
 constexpr size_t FZ_DYN_LDS = (size_t)EB * sizeof(int) + (size_t)(EB + CAPX) * sizeof(double);

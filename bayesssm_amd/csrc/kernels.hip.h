@@ -756,7 +756,8 @@ struct SegSmem {
     double bnd_terms[MAXBND][EL];    // the terms of every boundary lane (so a literal re-run never chases global memory)
     uint64_t seg_start[MAXBND + 1];
     long long red_min[NWV][2], red_max[NWV][2];
-    uint64_t lane_base[NT];          // every lane's hypothesis base (block_scan): a segment's base is its first lane's, read without a barrier round
+    uint64_t segbase[MAXBND + 1];    // hypothesis base of every segment = that of its first lane (published by block_scan: no barrier round later)
+    int wlastb[16];                  // per wave: its last lane is a boundary
     int smin[MAXBND + 1]; int smax[MAXBND + 1];
     int nb; int fail; int big;
     double sh4[16];
@@ -782,7 +783,8 @@ __device__ __forceinline__ PureC purec_compose(const PureC& f, const PureC& g)
 }
 
 template <int NW>
-__device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, bool isb, int& seg, int& nb_total, Pure& block_incl_last_seg)
+__device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, bool isb, int& seg, int& nb_total, Pure& block_incl_last_seg,
+                                              bool* prev_is_boundary = nullptr /* out: the lane in front of this one is a boundary lane */)
 {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const unsigned long long bal = __ballot(isb);
@@ -808,8 +810,10 @@ __device__ __forceinline__ Pure seg_excl_scan(SegSmem& sm, const Pure& leaf, boo
         if (last_is_b) { a.d0 = 0; a.d1 = 0; }                        // a boundary in the last lane: nothing is carried
         sm.wagg[wave] = a; sm.wflag[wave] = (bal != 0ull) ? 1 : 0;    // a boundary anywhere in the wave cuts the carry
         sm.wnb[wave] = __popcll(bal);
+        sm.wlastb[wave] = last_is_b ? 1 : 0;
     }
     __syncthreads();
+    if (prev_is_boundary) *prev_is_boundary = (lane > 0) ? (((bal >> (lane - 1)) & 1ull) != 0) : (wave > 0 && sm.wlastb[wave - 1] != 0);
     Pure carry; carry.d0 = 0; carry.d1 = 0;
     int segbase = 0;
     if (NW <= 4) {
@@ -950,8 +954,9 @@ __device__ __forceinline__ void block_scan(SegSmem& sm, const double (&v)[EL], d
     bs.isb = bs.leaf.kind != REC_PURE;
     bs.pleaf.d0 = (int64_t)(bs.leaf.o[0] - bs.leaf.base);
     bs.pleaf.d1 = (int64_t)(bs.leaf.o[1] - (bs.leaf.base + 1));
-    bs.exc = seg_excl_scan<NT / 64>(sm, bs.pleaf, bs.isb, bs.seg, bs.nb, bs.last_seg);
-    sm.lane_base[threadIdx.x] = bs.leaf.base;
+    bool prev_b = false;
+    bs.exc = seg_excl_scan<NT / 64>(sm, bs.pleaf, bs.isb, bs.seg, bs.nb, bs.last_seg, &prev_b);
+    if (!bs.isb && prev_b && bs.seg <= MAXBND) sm.segbase[bs.seg] = bs.leaf.base;      // the first lane of segment bs.seg (>= 1)
     // publish the boundaries in lane order
     if (bs.isb && bs.seg < MAXBND) {
         Rec& d = sm.bnd_rec[bs.seg];
@@ -1161,7 +1166,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
     //  resolve waits for the last record)
     int fb = NT;
     uint64_t seg1_base = 0;
-    if (bs.nb > 0) { fb = sm.bnd_lane[0]; if (fb + 1 < NT) seg1_base = sm.lane_base[fb + 1]; }
+    if (bs.nb > 0) { fb = sm.bnd_lane[0]; seg1_base = sm.segbase[1]; }       // (segbase[1]: only meaningful -- and only used -- when segment 1 has a lane)
     long long mn[2] = {(1ll << 40), (1ll << 40)}, mx[2] = {-(1ll << 40), -(1ll << 40)};
     if (!bs.isb && bs.seg <= 1) {
         const uint64_t sb = (bs.seg == 0) ? hb0 : (seg1_base & ~3ull);
@@ -1255,10 +1260,10 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
     if (sm.fail || bs.nb > MAXBND) return;
     // ---- side list: every boundary leaf + the PURE segment after it, with that segment's window ----
     for (int k = t; k <= MAXBND; k += NT) { sm.smin[k] = 0x7fffffff; sm.smax[k] = -0x7fffffff; }
-    // (a segment's hypothesis base is that of its first lane, the lane behind boundary seg - 1: sm.lane_base)
+    // (a segment's hypothesis base is that of its first lane: sm.segbase, published by block_scan)
     __syncthreads();
     if (!bs.isb && bs.seg >= 1) {
-        const uint64_t sb = sm.lane_base[sm.bnd_lane[bs.seg - 1] + 1] & ~3ull;
+        const uint64_t sb = sm.segbase[bs.seg] & ~3ull;
         long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
         long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
         long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
@@ -1275,7 +1280,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
         const Pure post = (k + 1 < bs.nb) ? sm.bnd_excl[k + 1] : bs.last_seg;
         e.d0 = post.d0; e.d1 = post.d1;
         const bool has_post = (sm.smin[k + 1] != 0x7fffffff);
-        e.post_base = has_post ? (sm.lane_base[t + 1] & ~3ull) : 0ull;       // (has_post: lane t + 1 is the segment's first lane)
+        e.post_base = has_post ? (sm.segbase[k + 1] & ~3ull) : 0ull;
         const long long lo = has_post ? (-(long long)lim - (long long)sm.smin[k + 1] + 4) : -(1ll << 30);
         const long long hi = has_post ? ((long long)lim - (long long)sm.smax[k + 1] - 4) : (1ll << 30);
         e.lo = (int32_t)(lo < -(1ll << 30) ? -(1ll << 30) : (lo > (1ll << 30) ? (1ll << 30) : lo));

@@ -61,3 +61,12 @@ print("   links %d" % r[8])
 r2 = np.array(list(st)).reshape(4, 16)[2]
 print("crossing block (B/4), P pass: boundaries %d; block_scan %d, tail entry %d, minmax2 %d, compose %d, barrier %d, to the end %d" % (
     r2[8], r2[11] - r2[10], r2[12] - r2[11], r2[3] - r2[12], r2[14] - r2[13], r2[15] - r2[14], r2[9] - r2[15]))
+
+lib.bssm_ctx_fused_endt.argtypes = [C.c_void_p, C.c_void_p]
+et = (C.c_longlong * 512)()
+_lib.check(lib.bssm_ctx_fused_endt(cx.handle, et))
+e = np.array(list(et))[:Bn]
+late = np.argsort(e)[::-1][:12]
+print("end of expansion (10 ns ticks after the earliest P publish): median %d, p90 %d, max %d; latest blocks: %s" % (
+    np.median(e) - p[2][:Bn].min(), np.percentile(e, 90) - p[2][:Bn].min(), e.max() - p[2][:Bn].min(),
+    ", ".join("%d (+%d)" % (int(b), e[b] - p[2][:Bn].min()) for b in late)))
