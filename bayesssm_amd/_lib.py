@@ -95,8 +95,9 @@ def load():
     lib.bssm_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
     lib.bssm_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.bssm_ctx_get_stamps.argtypes = [C.c_void_p, C.c_void_p]
-    lib.bssm_ctx_fused_stats.argtypes = [C.c_void_p, C.c_void_p]
-    lib.bssm_ctx_fused_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(lib, "bssm_ctx_fused_stats"):          # (absent only in an older build selected with BAYESSSM_AMD_LIB for an A/B)
+        lib.bssm_ctx_fused_stats.argtypes = [C.c_void_p, C.c_void_p]
+        lib.bssm_ctx_fused_stamps.argtypes = [C.c_void_p, C.c_void_p]
     lib.bssm_ctx_get_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bssm_resample_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]

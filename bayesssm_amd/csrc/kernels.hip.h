@@ -2311,6 +2311,9 @@ __device__ __forceinline__ void apply_tail(SegSmem& sm, int* Tl /* [EB] */, int&
 }
 
 
+// (The body below and apply_tail above are the same expansion: the multi-launch kernels keep it in ONE function -- split into head + tail
+//  the lean expansion kernel ran 39.6 instead of 35.1 us at N = 2^22 (same source otherwise, profiles/r03_h_*) -- and the fused kernel, which
+//  arrives with the exact states already in registers, calls apply_tail.)
 // LEAN (scalar state, no auxiliary log-weights to carry; grids that run several rounds of workgroups per CU): the registers of the
 // second state component and of the auxiliary values are not allocated, and CAP < CAPX outputs are staged -- together four
 // workgroups fit a CU instead of three (112 VGPRs, 40.7 KiB LDS).
@@ -2383,7 +2386,181 @@ __device__ __forceinline__ void apply_block(SegSmem& sm, uint64_t* tin /* [NT + 
         const bool good = block_resolve<MODE_P>(sm, bs, cinb, a.lim, a.w, a.nw, total, b0, ent);
         if (!good) { block_literal<MODE_P>(tin, cinb, a.w, a.nw, total, b0, st); ent = tin[t]; }
     }
-    apply_tail<KIND, STEP, CAP, LEAN>(sm, Tl, Tbegin, bidx, nblk, a, st, lx, nstage, v, ent, xs0, xs1, axs, call, us, Usys, dbg, stamper);
+    BSSM_STAMP(st, dbg, 3, 3, stamper);
+    // the reference chain itself, from the exact incoming state
+    int Tk[EL];
+    double c = b2d(ent);
+#pragma unroll
+    for (int k = 0; k < EL; k++) {
+        c = c + v[k];
+        const long long j = b0 + (long long)t * EL + k;
+        if (a.cum_out && j < a.nw) a.cum_out[j] = c;
+        int T;
+        if (j >= a.nw - 1) T = a.n;                                   // j < size-1 clamp (src/resampling.cpp:33,59)
+        else if (KIND == 1) T = count_le_systematic(c, a.n, Usys);
+        else if (KIND == 0) T = count_le_stratified(c, a.n, us);
+        else T = 0;
+        Tl[t * EL + k] = T;
+        Tk[k] = T;
+    }
+    if (KIND == 2) return;                                            // multinomial: k_multinomial searches cum_out
+    BSSM_STAMP(st, dbg, 3, 4, stamper);
+    // Outputs owned before this lane's first element: T of the lane's own exact incoming state (every lane evaluates it
+    // itself -- no LDS hand-off from the neighbouring lane, and the check below is complete before the barrier).
+    int tprev;
+    {
+        const long long jprev = b0 + (long long)t * EL - 1;
+        if (jprev < 0) tprev = 0;
+        else if (jprev >= a.nw - 1) tprev = a.n;                      // the clamp of src/resampling.cpp:33,59 already applied
+        else tprev = (KIND == 1) ? count_le_systematic(b2d(ent), a.n, Usys) : count_le_stratified(b2d(ent), a.n, us);
+    }
+    int maxcnt = 0;
+    {
+        int p = tprev;
+#pragma unroll
+        for (int k = 0; k < EL; k++) { maxcnt = (Tk[k] - p) > maxcnt ? (Tk[k] - p) : maxcnt; p = Tk[k]; }
+    }
+    if (maxcnt > 64) sm.big = 1;                                      // (cleared at entry; barriers in between)
+    if (t == 0) { Tbegin = tprev; if (bidx == a.lead) st->out_lo = tprev; }
+    if (t == NT - 1 && bidx == a.last) st->out_hi = Tk[EL - 1];
+    __syncthreads();
+    BSSM_STAMP(st, dbg, 3, 7, stamper);
+    const int Tb = Tbegin, Te = Tl[EB - 1];
+    int* anc = a.anc_out ? a.anc_out + (long long)call * a.anc_stride : nullptr;
+    const double invN = 1.0 / (double)a.n;
+    double acc0 = 0.0, acc1 = 0.0;
+    // Expansion.  Each element owns the outputs [T_prev, T) (src/resampling.cpp:30-37).  Common case (no element
+    // owns more than 64 outputs): every lane stores its elements' particles straight to the outputs they own --
+    // neighbouring lanes own neighbouring output ranges, and nothing has to be gathered.  Otherwise (degenerate
+    // weights: a few particles own almost everything): all lanes share the work through a binary search in the counts.
+    const int any_big = sm.big;
+    bool step_in_place = false; (void)step_in_place;
+    BSSM_STAMP(st, dbg, 3, 8, stamper);
+    if (!any_big) {
+        // Scattered 8-byte stores cost the CU one address per lane (64 cache lines per wave instruction): with the
+        // particles going straight to HBM that address traffic, not the bytes, bounded this stage.  Plain case
+        // (scalar state, nothing else to carry): scatter into LDS, then store the block's output range coalesced.
+        // (the second state component and the auxiliary log-weights are staged the same way when the launch provides room)
+        const int need = (d2 ? 2 : 1) + (aux ? 1 : 0);
+        const bool stage = (lx != nullptr) && a.xdst && !anc && need <= nstage && (Te - Tb) <= CAP;
+        double* lx1 = lx + CAP;                                    // second state component
+        double* lxa = lx + (d2 ? 2 : 1) * CAP;                     // auxiliary log-weights
+        int Tp[EL], Ts[EL];                                        // all the counts first: one LDS round trip, not EL
+#pragma unroll
+        for (int k = 0; k < EL; k++) { const int e = ebase + 64 * k; Ts[k] = Tl[e]; Tp[k] = (e == 0) ? Tb : Tl[e - 1]; }
+        if (stage) {
+            // one loop over "j-th output of every element" with the EL stores predicated, instead of EL short loops
+            // (a divergent loop trip costs two scalar branches and a dozen instructions)
+            int cmax = 0;
+#pragma unroll
+            for (int k = 0; k < EL; k++) { Ts[k] -= Tp[k]; Tp[k] -= Tb; cmax = Ts[k] > cmax ? Ts[k] : cmax; }     // counts, staging offsets
+            for (int j = 0; __any(j < cmax); j++) {
+#pragma unroll
+                for (int k = 0; k < EL; k++) {
+                    if (j < Ts[k]) {
+                        lx[Tp[k] + j] = xs0[k];
+                        if (d2) lx1[Tp[k] + j] = xs1[k];
+                        if (aux) lxa[Tp[k] + j] = axs[k];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < EL; k++) {
+                const long long src = b0 + ebase + 64 * k;
+                for (int i = Tp[k]; i < Ts[k]; i++) {
+                    if (anc) anc[i] = (int)(src + 1);                    // 1-based (src/resampling.cpp:36,62)
+                    if (a.xdst) {
+                        a.xdst[i] = xs0[k];
+                        if (d2) a.xdst[a.xstride + i] = xs1[k];
+                    }
+                    if (aux) a.auxdst[i] = axs[k];
+                }
+            }
+        }
+        // the state estimate sums the block's outputs in output order, strided over the lanes (every path does)
+        BSSM_STAMP(st, dbg, 3, 9, stamper);
+        if (a.xdst) {
+            __syncthreads();
+            BSSM_STAMP(st, dbg, 3, 10, stamper);
+            if (stage) {
+                // all the LDS reads first, then the stores (a read-store pair per trip waited ~450 cycles a trip)
+                constexpr int R = CAP / NT;
+                double xv[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; xv[r] = (i < Te) ? lx[i - Tb] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < R; r++) { const int i = Tb + t + NT * r; if (i < Te) { if (!STEP) bulk_store8<BSSM_ST_X>(a.xdst + i, xv[r]); acc0 += xv[r] * invN; } }
+                if constexpr (STEP) {
+                    // the next observation's transition + weight on the staged particles, a PAIR of outputs per lane (the
+                    // generator gives two normals per block, keyed by the pair's index -- exactly k_step's arithmetic);
+                    // a pair cut by the range's ends is finished by the neighbouring workgroup
+                    constexpr int R2 = (CAP / 2 + 1 + NT - 1) / NT;
+                    const int q0 = Tb >> 1;
+#pragma unroll
+                    for (int r = 0; r < R2; r++) {
+                        const int q = q0 + t + NT * r, i0 = 2 * q, i1 = i0 + 1;
+                        const bool v0 = (i0 >= Tb && i0 < Te), v1 = (i1 >= Tb && i1 < Te);
+                        if (v0 || v1) {
+                            double x0 = v0 ? lx[i0 - Tb] : 0.0, x1 = v1 ? lx[i1 - Tb] : 0.0;
+                            double z0, z1;
+                            if (a.step_ns.arr) { z0 = v0 ? a.step_ns.arr[i0] : 0.0; z1 = v1 ? a.step_ns.arr[i1] : 0.0; }
+                            else normal_pair(a.step_ns.key, a.step_ns.purpose, a.step_ns.call, 0, (uint32_t)q, z0, z1);
+                            if (a.step_model == 1) { x0 = Model<1>::transition(x0, z0, a.step_par); x1 = Model<1>::transition(x1, z1, a.step_par); }
+                            else { x0 = Model<0>::transition(x0, z0, a.step_par); x1 = Model<0>::transition(x1, z1, a.step_par); }
+                            const double l0 = r_dnorm_log(a.step_y, x0, a.step_par.sy, a.step_par.log_sy);
+                            const double l1 = r_dnorm_log(a.step_y, x1, a.step_par.sy, a.step_par.log_sy);
+                            if (v0 && v1) {
+                                double2 qx; qx.x = x0; qx.y = x1; *reinterpret_cast<double2*>(a.xdst + i0) = qx;
+                                double2 ql; ql.x = l0; ql.y = l1; *reinterpret_cast<double2*>(a.step_lw + i0) = ql;
+                            } else if (v0) { a.xdst[i0] = x0; a.step_lw[i0] = l0; }
+                            else { a.xdst[i1] = x1; a.step_lw[i1] = l1; }
+                        }
+                    }
+                }
+                if (d2) for (int i = Tb + t; i < Te; i += NT) { const double x1 = lx1[i - Tb]; a.xdst[a.xstride + i] = x1; acc1 += x1 * invN; }
+                if (aux) for (int i = Tb + t; i < Te; i += NT) a.auxdst[i] = lxa[i - Tb];
+            } else {
+                for (int i = Tb + t; i < Te; i += NT) {
+                    acc0 += a.xdst[i] * invN;
+                    if (d2) acc1 += a.xdst[a.xstride + i] * invN;
+                }
+                if constexpr (STEP) step_in_place = true;
+            }
+        }
+    } else {
+        const double2 r = expand_by_search(Tl, anc, a.xsrc, a.xdst, a.dim, a.xstride, a.auxsrc, a.auxdst, b0, Tb, Te, invN);
+        acc0 = r.x; acc1 = r.y;
+        if constexpr (STEP) step_in_place = true;
+    }
+    if constexpr (STEP) {
+        if (step_in_place) {
+            // (the resampled particles of this workgroup's range went to global memory -- too many outputs to stage, or
+            //  degenerate weights: the next observation's transition + weight in place, after everyone has read them)
+            __syncthreads();
+            for (int q = (Tb >> 1) + t; 2 * q < Te; q += NT) {
+                const int i0 = 2 * q, i1 = i0 + 1;
+                const bool v0 = (i0 >= Tb && i0 < Te), v1 = (i1 >= Tb && i1 < Te);
+                if (v0 || v1) {
+                    double x0 = v0 ? a.xdst[i0] : 0.0, x1 = v1 ? a.xdst[i1] : 0.0;
+                    double z0, z1;
+                    if (a.step_ns.arr) { z0 = v0 ? a.step_ns.arr[i0] : 0.0; z1 = v1 ? a.step_ns.arr[i1] : 0.0; }
+                    else normal_pair(a.step_ns.key, a.step_ns.purpose, a.step_ns.call, 0, (uint32_t)q, z0, z1);
+                    if (a.step_model == 1) { x0 = Model<1>::transition(x0, z0, a.step_par); x1 = Model<1>::transition(x1, z1, a.step_par); }
+                    else { x0 = Model<0>::transition(x0, z0, a.step_par); x1 = Model<0>::transition(x1, z1, a.step_par); }
+                    if (v0) { a.xdst[i0] = x0; a.step_lw[i0] = r_dnorm_log(a.step_y, x0, a.step_par.sy, a.step_par.log_sy); }
+                    if (v1) { a.xdst[i1] = x1; a.step_lw[i1] = r_dnorm_log(a.step_y, x1, a.step_par.sy, a.step_par.log_sy); }
+                }
+            }
+        }
+    }
+    BSSM_STAMP(st, dbg, 3, 5, stamper);
+    if (a.se_part) {
+        acc0 = block_sum(acc0, sm.sh4);
+        if (d2) acc1 = block_sum(acc1, sm.sh4);
+        if (t == 0) { a.se_part[(long long)bidx * a.dim] = acc0; if (d2) a.se_part[(long long)bidx * a.dim + 1] = acc1; }
+    }
+    BSSM_STAMP(st, dbg, 3, 6, stamper);
 }
 
 
