@@ -156,6 +156,8 @@ class Context:
         self.max_dim = max_dim
         if os.environ.get("BAYESSSM_AMD_FUSED") is not None:        # A/B switch for the dev tools: the per-context option `fused`
             check(lib.bssm_ctx_set_option(h, 9, int(os.environ["BAYESSSM_AMD_FUSED"])))
+        if os.environ.get("BAYESSSM_AMD_FUSED_PREFETCH") is not None:
+            check(lib.bssm_ctx_set_option(h, 10, int(os.environ["BAYESSSM_AMD_FUSED_PREFETCH"])))
 
     @property
     def handle(self):

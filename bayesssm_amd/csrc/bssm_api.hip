@@ -1080,10 +1080,11 @@ extern "C" int bssm_ctx_fused_stamps(bssm_ctx* c, long long* out /* [2][24] */)
     return BSSM_OK;
 }
 
-extern "C" int bssm_ctx_fused_endt(bssm_ctx* c, long long* out /* [512] */)
+extern "C" int bssm_ctx_fused_endt(bssm_ctx* c, long long* out /* [2][512]: end, start */)
 {
     if (!c || !out || !c->fz) ARGFAIL("bssm_ctx_fused_endt: NULL argument");
     HIPCHK(hipMemcpy(out, c->fz->endt, sizeof(c->fz->endt), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out + FZ_MAXB, c->fz->startt, sizeof(c->fz->startt), hipMemcpyDeviceToHost));
     return BSSM_OK;
 }
 

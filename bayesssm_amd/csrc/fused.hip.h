@@ -57,6 +57,7 @@ struct FusedWs {
     BlockRec brec_priv[2][MAXB];                 // (four planes each, BREC_STRIDE apart)
     SideList side_priv[2][FZ_MAXB];
     long long stamps[2][24];
+    long long startt[FZ_MAXB];                   // dev tool: wall clock at every block's first instruction
     long long endt[FZ_MAXB];                     // dev tool: wall clock at the end of every block's expansion
     long long pubt[4][FZ_MAXB];                  // dev tool: wall clock (100 MHz) of every block's three publishes; [3][8..10] resolver's gather-done times                     // dev tool (make DEV=1): clock64() at the stages of a typical worker [0] / of the resolver [1], last launch
 };
@@ -308,19 +309,21 @@ __device__ __forceinline__ uint64_t fz_resolve_duty(SegSmem& sm, ResolveSmem& rs
 __host__ __device__ __forceinline__ int fz_resolver_block(int B) { return (5 * B) / 16; }
 
 // The normals of transition call `call` for this lane's EL slots, to HBM (the next launch reads them as it reads injected draws).
-__device__ __forceinline__ void fz_draw_next(const FusedArgs& g, long long j0, long long N)
+__device__ __forceinline__ void fz_draw_next(const FusedArgs& g, long long j0, long long N, const int prio_after = 1)
 {
     if (!g.znext) return;
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int i = 0; i < EL / 2; i++) {
         const long long j = j0 + 2 * i;
         if (j < N) {
             double z0, z1;
             normal_pair(g.ns.key, g.ns.purpose, g.znext_call, 0, (uint32_t)(j >> 1), z0, z1);
-            if (j + 1 < N) { double2 q; q.x = z0; q.y = z1; *reinterpret_cast<double2*>(g.znext + j) = q; }
+            if (j + 1 < N) bulk_store16<1>(g.znext + j, z0, z1);      // write-through: nothing of it is left dirty in L2 for the end-of-kernel write-back
             else g.znext[j] = z0;
         }
     }
+    if (prio_after == 3) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------
@@ -340,10 +343,13 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
     // workgroups of its CU wins the VALU arbitration -- and (b) does not sit where the cumulative weight crosses a power of two
     // (blocks B/2, B/4, ...: their records take the longer path): block 5B/16, at cum ~ 0.31
     const bool resolver = (bidx == fz_resolver_block(B));
-    if (resolver) __builtin_amdgcn_s_setprio(3);
+    // wave priorities: the resolver above everybody (its duties are on every workgroup's critical path), ordinary work 1, the
+    // next observation's normals (fz_draw_next, drawn while a workgroup waits) 0: they only take VALU slots nobody else wants
+    if (resolver) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
     const bool fz_stamper = (t == 0) && (resolver || bidx == ((B > 100) ? 100 : 0)); const int fz_row = resolver ? 1 : 0; (void)fz_stamper; (void)fz_row;
     FZ_STAMP(0);
 #ifdef BSSM_DEV_STAMPS
+    if (t == 0) g.ws->startt[bidx] = (long long)wall_clock64();
 #define FZ_PUBT(k) do { if (t == 0) g.ws->pubt[k][bidx] = (long long)wall_clock64(); } while (0)
 #define FZ_GDONE(k) do { if (t == 0) g.ws->pubt[3][8 + (k)] = (long long)wall_clock64(); } while (0)
 #else

@@ -11,6 +11,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 rng = np.random.default_rng(1)
 cx = B.Context(0, 1 << 20, 1)
 cx.set_option("debug_stop", 99)
+if os.environ.get("FZ_PREFETCH"):
+    cx.set_option("fused_prefetch", 1)
 m = B.models.linear_gaussian()
 x, ys = 0.0, []
 for _ in range(30):
@@ -63,9 +65,13 @@ print("crossing block (B/4), P pass: boundaries %d; block_scan %d, tail entry %d
     r2[8], r2[11] - r2[10], r2[12] - r2[11], r2[3] - r2[12], r2[14] - r2[13], r2[15] - r2[14], r2[9] - r2[15]))
 
 lib.bssm_ctx_fused_endt.argtypes = [C.c_void_p, C.c_void_p]
-et = (C.c_longlong * 512)()
+et = (C.c_longlong * 1024)()
 _lib.check(lib.bssm_ctx_fused_endt(cx.handle, et))
 e = np.array(list(et))[:Bn]
+st0 = np.array(list(et))[512:512 + Bn]
+print("block start times (10 ns ticks after the first): median %d, p90 %d, max %d; first-round blocks (0..255) median %d, second-round (256..511) median %d; kernel span first start -> last end %d" % (
+    np.median(st0) - st0.min(), np.percentile(st0, 90) - st0.min(), st0.max() - st0.min(), np.median(st0[:256]) - st0.min(), np.median(st0[256:]) - st0.min() if Bn > 256 else -1, e.max() - st0.min()))
+print("partials publish relative to the first start: median %d, max %d" % (np.median(p[0][:Bn]) - st0.min(), p[0][:Bn].max() - st0.min()))
 late = np.argsort(e)[::-1][:12]
 print("end of expansion (10 ns ticks after the earliest P publish): median %d, p90 %d, max %d; latest blocks: %s" % (
     np.median(e) - p[2][:Bn].min(), np.percentile(e, 90) - p[2][:Bn].min(), e.max() - p[2][:Bn].min(),

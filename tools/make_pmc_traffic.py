@@ -6,7 +6,8 @@ import csv, json, sys, collections, os
 sys.path.insert(0, '.')
 from bench import kernel_source_hash
 
-LABEL = [("k_step<", "k_step<trans+weight>"), ("k_lw_partials", "k_lw_partials"), ("k_resolve<0>", "k_resolve<W>"), ("k_resolve<1>", "k_resolve<P>"),
+LABEL = [("k_obs<0, 1>", "k_obs<systematic>"), ("k_obs<0, 0>", "k_obs<stratified>"), ("k_obs<1, 1>", "k_obs<systematic>"), ("k_obs<1, 0>", "k_obs<stratified>"),
+         ("k_step<", "k_step<trans+weight>"), ("k_lw_partials", "k_lw_partials"), ("k_resolve<0>", "k_resolve<W>"), ("k_resolve<1>", "k_resolve<P>"),
          ("k_local<0, true", "k_weights(normalize+local<W>)"), ("k_local<1, false, true", "k_local<P>(+resolve<W>)"), ("k_local<1, false, false", "k_local<P>"),
          ("k_apply<1, true, false", "k_apply<systematic>(+resolve<P>)"), ("k_apply<0, true, false", "k_apply<stratified>(+resolve<P>)"),
          ("k_apply<1, false, false", "k_apply<systematic>"), ("k_apply<0, false, false", "k_apply<stratified>")]
@@ -19,7 +20,7 @@ def per_kernel(path, counter):
             continue
         name = r["Kernel_Name"].replace("void bssm::", "").replace("bssm::", "")
         for pat, lab in LABEL:
-            if name.startswith(pat) and int(r["Grid_Size"]) >= 256 * 256:       # the N = 2^20 launches only
+            if name.startswith(pat) and int(r["Grid_Size"]) >= 256 * 512:       # the N = 2^20 launches only
                 acc[lab].append(float(r["Counter_Value"]))
                 break
     return {k: sum(v) / len(v) for k, v in acc.items()}
