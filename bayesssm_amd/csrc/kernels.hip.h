@@ -3,20 +3,25 @@
 // Hot path of the reference, per observation (R/particle_filter_core.R:123-246):
 //   transition_fn -> weight_fn -> max/exp/sum normalise -> loglik, ESS ->
 //   resample_fn (src/resampling.cpp) -> gather -> state estimate.
-// Kernel map (one launch each, all on the context's stream; 6 launches per observation with resampling):
-//   k_step / k_step_sir   transition_fn + weight_fn + per-block (max, sum exp, sum exp^2) partials   :127,:177-183
-//   k_local<W, from_lw>   w = exp(lw - max)/sum (:205-207); loglik / ESS / resample decision from the partials
-//                         (:208-218); block records of the exact sequential sum(w)               src/resampling.cpp:20
-//   k_resolve<W>          exact total = sum(w) (one workgroup)                                   src/resampling.cpp:20
-//   k_local<P>            block records of cumsum(w / total)                                     src/resampling.cpp:24-25
-//   k_resolve<P>          exact incoming state of every block (one workgroup)
-//   k_apply<kind>         exact cum_sum -> output counts -> ancestors -> particles[indices, ]    src/resampling.cpp:28-37, R/resampling.R:40
+// Kernel map of the MULTI-LAUNCH path (all on the context's stream; 4 launches per observation with resampling up to 2^20 particles,
+// 6 above; the fused path -- fused.hip.h, ONE launch per observation -- runs the same *_block bodies):
+//   k_step / k_step_sir   transition_fn + weight_fn + per-block (max, sum exp, sum exp^2) partials, grid max by atomics   :127,:177-183
+//   k_weights             = k_local<W, from_lw>: w = exp(lw - max)/sum (:205-207); loglik / ESS / resample decision from the
+//                         partials (:208-218); block records of the exact sequential sum(w)          src/resampling.cpp:20
+//   k_local<P>(+resolve)  every workgroup resolves the W records itself -> exact total; block records of cumsum(w / total)
+//                                                                                                     src/resampling.cpp:24-25
+//   k_apply<kind>(+resolve) every workgroup resolves the P records up to itself -> its exact incoming state; exact cum_sum ->
+//                         output counts -> ancestors -> particles[indices, ]                          src/resampling.cpp:28-37, R/resampling.R:40
+//   k_resolve_all<W|P>    grids above 512 blocks: one 1024-thread workgroup resolves a pass and emits every block's state
+//                         (k_resolve: the round-1 resolver, behind option inkernel_resolve = 0)
 //   k_multinomial         inverse-CDF search on the exact cum_sum                                src/resampling.cpp:11 (distributional)
+//   k_multinomial_r       Rcpp::sample's own algorithm on R's unif_rand() stream (parity mode)   src/resampling.cpp:11
 //   k_carry               no resample at this observation: carry particles, sum(x * w)           :238
 //   k_move                resample_move_filter's random-walk Metropolis move                     :226-234
 //   k_bsum, k_plan        stand-alone resampler front end (validation, approximate block prefixes)
 //   k_pf_batch            many small filters per launch: one workgroup = one whole filter (all T observations on chip),
 //                         built from the same *_block bodies as the kernels above
+// mv.hip.h: the multivariate linear-Gaussian family's model kernels; multi.hip.h: K filters per launch (blockIdx.y = filter).
 // Particles are SoA: x[dim][N] doubles; weights/log-weights [N]; ancestors int32.
 //
 // All arithmetic that the reference defines is done in fp64 with contraction
