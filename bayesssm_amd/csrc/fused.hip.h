@@ -139,12 +139,16 @@ __device__ __forceinline__ bool fz_wait_words(const fz_u64* mine, uint32_t tag, 
 
 // ---- sinks of block_record_tail ---------------------------------------------------------------------------------------
 // The block's own terms for the in-order fallback live in LDS (nothing of a fused run's weights is in HBM).
-__device__ __attribute__((noinline)) void fz_block_literal(uint64_t* tin /* LDS [NT] */, uint64_t cin, double* terms /* LDS [EB] */, const double* v /* this lane's EL terms */,
+// (the lane's terms travel BY VALUE: a pointer to the caller's register array handed to an out-of-line function forces that
+//  array into scratch memory for the whole kernel -- 64 B a lane stored by every launch and written back to HBM at its end,
+//  8 MiB per observation at N = 2^20, seen as WRITE_SIZE twice the algorithmic bytes)
+struct LaneTerms { double a[EL]; };
+__device__ __attribute__((noinline)) void fz_block_literal(uint64_t* tin /* LDS [NT] */, uint64_t cin, double* terms /* LDS [EB] */, const LaneTerms v /* this lane's EL terms */,
                                                            DevState* st)
 {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < EL; k++) terms[t * EL + k] = v[k];
+    for (int k = 0; k < EL; k++) terms[t * EL + k] = v.a[k];
     __syncthreads();
     if (t == 0) {
         double c = b2d(cin);
@@ -157,12 +161,19 @@ __device__ __attribute__((noinline)) void fz_block_literal(uint64_t* tin /* LDS 
     }
     __syncthreads();
 }
+__device__ __forceinline__ LaneTerms fz_lane_terms(const double (&v)[EL])
+{
+    LaneTerms r;
+#pragma unroll
+    for (int k = 0; k < EL; k++) r.a[k] = v[k];
+    return r;
+}
 
 struct FusedRecSink {
     fz_u64* rec_planes;            // [FZ_KREC][FZ_MAXB]
     fz_u64* side_base;             // [FZ_MAXB][FZ_MAXSIDE][FZ_KSIDE]
     int bidx; uint32_t tag;
-    double* terms; const double* v; DevState* st;
+    double* terms; DevState* st;
     __device__ __forceinline__ void rec(const BlockRec& br) const
     {
         uint32_t w[FZ_KREC];
@@ -179,7 +190,7 @@ struct FusedRecSink {
 #pragma unroll
         for (int q = 0; q < FZ_KSIDE; q++) fz_put(dst + q, tag, w[q]);
     }
-    __device__ __forceinline__ void literal(uint64_t* tin, uint64_t cin) const { fz_block_literal(tin, cin, terms, v, st); }
+    __device__ __forceinline__ void literal(uint64_t* tin, uint64_t cin, const double (&v)[EL]) const { fz_block_literal(tin, cin, terms, fz_lane_terms(v), st); }
 };
 
 // ---- arguments -----------------------------------------------------------------------------------------------------
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
     if (status & FZ_ST_STOP) return;
     FZ_STAMP(6);
     // ---- W pass: the block's record of the exact sequential sum(w) (src/resampling.cpp:20,47) ----
-    FusedRecSink sink; sink.bidx = bidx; sink.tag = g.tag; sink.terms = lx; sink.v = v; sink.st = st;
+    FusedRecSink sink; sink.bidx = bidx; sink.tag = g.tag; sink.terms = lx; sink.st = st;
     {
         BlockScan bsw;
         block_scan<MODE_W>(sm, v, a_in, g.lim, bsw);
@@ -666,7 +677,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
     uint64_t ent;
     {
         const bool good = block_resolve<MODE_P>(sm, bs, cinb, g.lim, nullptr, 0, total, b0, ent);
-        if (!good) { fz_block_literal(tin, cinb, lx, v, st); ent = tin[t]; }
+        if (!good) { fz_block_literal(tin, cinb, lx, fz_lane_terms(v), st); ent = tin[t]; }
     }
     FZ_STAMP(17);
     // the particles in the expansion's lane-interleaved layout (element wave * 64 * EL + 64 k + lane), through LDS

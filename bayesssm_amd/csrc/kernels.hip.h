@@ -1139,7 +1139,7 @@ struct GlobalRecSink {
     __device__ __forceinline__ void rec(const BlockRec& br) const { store_brec(brec, bidx, br, bstride); }
     __device__ __forceinline__ void side(int k, const SideEntry& e) const { this->side_list()[k] = e; }
     __device__ __forceinline__ SideEntry* side_list() const { return sides[bidx].e; }
-    __device__ __forceinline__ void literal(uint64_t* tin, uint64_t cin) const { block_literal<MODE>(tin, cin, w, nw, total, b0, st); }
+    __device__ __forceinline__ void literal(uint64_t* tin, uint64_t cin, const double (&)[EL]) const { block_literal<MODE>(tin, cin, w, nw, total, b0, st); }
 };
 
 // The block's record for the grid-level resolve, from its scan (see k_local below for the four cases).
@@ -1155,7 +1155,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
         // exact incoming state (+0): resolve now and publish the exact outgoing state
         uint64_t ent;
         bool good = block_resolve<MODE>(sm, bs, 0ull, lim, nullptr, 0, 1.0, 0, ent);
-        if (!good) { sink.literal(tin, 0ull); ent = tin[t]; }
+        if (!good) { sink.literal(tin, 0ull, v); ent = tin[t]; }
         if (t == NT - 1) {
             double c = b2d(ent);
 #pragma unroll
