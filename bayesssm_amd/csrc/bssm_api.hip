@@ -1095,6 +1095,13 @@ extern "C" int bssm_ctx_fused_pubt(bssm_ctx* c, long long* out /* [4][512] */)
     return BSSM_OK;
 }
 
+extern "C" int bssm_ctx_fused_waket(bssm_ctx* c, long long* out /* [3][512] */)
+{
+    if (!c || !out || !c->fz) ARGFAIL("bssm_ctx_fused_waket: NULL argument");
+    HIPCHK(hipMemcpy(out, c->fz->waket, sizeof(c->fz->waket), hipMemcpyDeviceToHost));
+    return BSSM_OK;
+}
+
 extern "C" int bssm_ctx_fused_stats(bssm_ctx* c, long long* out /* [4]: runs, launches, stand-downs (unsupported record), time-outs */)
 {
     if (!c || !out) ARGFAIL("bssm_ctx_fused_stats: NULL argument");

@@ -59,6 +59,7 @@ struct FusedWs {
     long long stamps[2][24];
     long long startt[FZ_MAXB];                   // dev tool: wall clock at every block's first instruction
     long long endt[FZ_MAXB];                     // dev tool: wall clock at the end of every block's expansion
+    long long waket[3][FZ_MAXB];                 // dev tool: wall clock at which every block had its three answers
     long long pubt[4][FZ_MAXB];                  // dev tool: wall clock (100 MHz) of every block's three publishes; [3][8..10] resolver's gather-done times                     // dev tool (make DEV=1): clock64() at the stages of a typical worker [0] / of the resolver [1], last launch
 };
 
@@ -363,9 +364,11 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
     if (t == 0) g.ws->startt[bidx] = (long long)wall_clock64();
 #define FZ_PUBT(k) do { if (t == 0) g.ws->pubt[k][bidx] = (long long)wall_clock64(); } while (0)
 #define FZ_GDONE(k) do { if (t == 0) g.ws->pubt[3][8 + (k)] = (long long)wall_clock64(); } while (0)
+#define FZ_WAKE(k) do { if (t == 0) g.ws->waket[k][bidx] = (long long)wall_clock64(); } while (0)
 #else
 #define FZ_PUBT(k) do { } while (0)
 #define FZ_GDONE(k) do { } while (0)
+#define FZ_WAKE(k) do { } while (0)
 #endif
     const long long b0 = (long long)bidx * EB, j0 = b0 + (long long)t * EL;
     const long long N = g.N;
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         M = b2d(mk64(fs.slot[0], fs.slot[1])); S = b2d(mk64(fs.slot[2], fs.slot[3])); a_in = b2d(mk64(fs.slot[7], fs.slot[8]));
         status = fs.slot[6];
     }
-    FZ_STAMP(5);
+    FZ_STAMP(5); FZ_WAKE(0);
     if (status & (FZ_ST_DEAD | FZ_ST_BAIL)) return;
     const bool doit = status & FZ_ST_DOIT;
     // ---- phase B: w = exp(lw - max) / sum (:205-207) ----
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         if (fs.slot[2] & (FZ_ST_BAIL | FZ_ST_STOP)) return;
         total = b2d(mk64(fs.slot[0], fs.slot[1]));
     }
-    FZ_STAMP(11);
+    FZ_STAMP(11); FZ_WAKE(1);
     // ---- P pass: prob = w / total, the block's record of cumsum(prob) (src/resampling.cpp:24-25,51-52) ----
     const double a_in_p = a_in / total;
 #pragma unroll
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         if (fs.slot[2] & FZ_ST_BAIL) return;
         cinb = mk64(fs.slot[0], fs.slot[1]);
     }
-    FZ_STAMP(16);
+    FZ_STAMP(16); FZ_WAKE(2);
     // ---- phase D: exact cum_sum, output counts, ancestors, particles[indices, ] (src/resampling.cpp:28-37,55-63) ----
     uint64_t ent;
     {

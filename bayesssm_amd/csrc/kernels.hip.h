@@ -748,6 +748,11 @@ __device__ __forceinline__ int walk_chain_regs(const WalkFn& w, int nent, uint64
     return j;
 }
 
+// (Round 3 also tried the links' constants in LDS, read at wave-uniform addresses so that every lane evaluates every link and the state
+//  never leaves the vector registers -- no v_readlane, one uniform branch per four links.  With a provably uniform address the compiler
+//  moved the chain to the scalar unit (16 v_readfirstlane a link: +3.5 us per resolve); kept on the vector unit by an opaque zero in the
+//  index it ran 0.3 us per resolve SLOWER than walk_chain_regs (N = 2^20: k_local<P> 11.35 -> 11.8 us, k_apply 15.2 -> 15.45, the fused
+//  launch 47.8 -> 48.3): the LDS write -> read turn-around and 16 ds_read per four links cost what the readlanes cost.  Removed.)
 __device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int off)
 {
     int lo = (int)(uint32_t)(uint64_t)v, hi = (int)(uint32_t)((uint64_t)v >> 32);
@@ -1208,6 +1213,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
         const uint64_t po = pbase + (uint64_t)t + ((fb == 0) ? 0ull : (uint64_t)((t & 1) ? ex0.d1 : ex0.d0));
         bool done1 = false;
         uint64_t fo = 0; long long flo = 0, fhi = 0;
+        BSSM_STAMP(st, dbg, 2, 5, stamper);
         if (bs.nb == 1 && leaf.kind == REC_X1) {
             // r = rec_compose(pre, leaf)
             bool ok = true;
@@ -1223,6 +1229,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
                 fo = os + (uint64_t)(q4 >> 1); flo = (long long)(int32_t)lo; fhi = (long long)(int32_t)hi;
             }
             ok = __all(ok);                                       // (lanes 0..3 are the active ones here)
+            BSSM_STAMP(st, dbg, 2, 6, stamper);
             if (ok && fb < NT - 1) {
                 // r = rec_compose(r, post),  post = pure_to_rec(last_seg, seg1_base, ...)
                 const uint64_t gbase = seg1_base & ~3ull;
@@ -1241,6 +1248,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
             }
             done1 = ok;
         }
+        BSSM_STAMP(st, dbg, 2, 7, stamper);
         // lane 0 collects the four outgoing states (of the composite, or of pre) and publishes the record
         const uint64_t src = done1 ? fo : po;
         const uint64_t o1 = (uint64_t)dpp_i64<0x55, 0xf>((long long)src, (long long)src), o2 = (uint64_t)dpp_i64<0xAA, 0xf>((long long)src, (long long)src),

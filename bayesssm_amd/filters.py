@@ -252,6 +252,7 @@ def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
         return particle_filter_closures(y, num_particles, init_fn, transition_fn, log_likelihood_fn, None, None, obs_times, "BPF",
                                         resample_algorithm, resample_fn, threshold, return_particles, **extra, **kwargs)
     r_seed = kwargs.pop("r_seed", None)
+    r_stream = kwargs.pop("r_stream", None)          # an rrng.RRandom positioned where R's generator stands before this call
     ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
     model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
     if model == "lgmv":                      # multivariate linear-Gaussian family: the descriptor packs its matrices for this parameter draw
@@ -259,38 +260,52 @@ def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
         return particle_filter_core(y, num_particles, model, theta, "BPF", obs_times, resample_algorithm, resample_fn,
                                     threshold, return_particles, **ctl)
     theta = models.theta_from_kwargs((init_fn, transition_fn, log_likelihood_fn), kwargs)
-    if r_seed is not None:
+    if r_seed is not None or r_stream is not None:
+        if r_seed is not None and r_stream is not None:
+            raise ValueError("r_seed and r_stream are mutually exclusive")
+        from .rrng import RRandom
         return _r_seeded_bootstrap(y, num_particles, model, theta, obs_times, resample_algorithm, resample_fn, threshold,
-                                   return_particles, int(r_seed), ctl)
+                                   return_particles, RRandom(int(r_seed)) if r_seed is not None else r_stream, ctl)
     return particle_filter_core(y, num_particles, model, theta, "BPF", obs_times, resample_algorithm, resample_fn,
                                 threshold, return_particles, **ctl)
 
 
-def _r_seeded_bootstrap(y, N, model, theta, obs_times, ra, rf, threshold, return_particles, r_seed, ctl):
-    """bootstrap_filter(..., r_seed = s): the run R makes after `set.seed(s)` when the closures have the README's form
-    (rrng.r_seeded_draws): the draws come from the R-compatible host generator in R's order and enter through the
+def _r_seeded_bootstrap(y, N, model, theta, obs_times, ra, rf, threshold, return_particles, g, ctl, guess=None):
+    """bootstrap_filter(..., r_seed = s) / (..., r_stream = g): the run R makes from the generator's position (after `set.seed(s)`,
+    or wherever a longer R session -- a whole pmmh() call -- has left it) when the closures have the README's form
+    (rrng.r_stream_draws): the draws come from the R-compatible host generator in R's order and enter through the
     parity mode.  Whether uniforms are consumed at an observation depends on that observation's resample decision, so
     the draw sequence is the fixed point of "assume decisions -> draw -> run -> read decisions" (at most T rounds; one
-    round for SIS / SISR).  By construction, not verified against R here (no R in this image): R's streams are pinned by
-    R's published known answers, the filter arithmetic by the parity tests."""
-    from .rrng import r_seeded_draws
+    round for SIS / SISR); every round starts from the same generator state and the last one leaves the generator exactly where
+    R's stands after the call.  R's streams are pinned by R's published known answers, the filter arithmetic by the parity tests,
+    and the two together by the README's printed PMMH table (tests/test_gpu_readme_r_stream.py)."""
+    from .rrng import r_stream_draws
     if model not in ("lg", "ar1sin"):
-        raise ValueError("r_seed: the scalar Gaussian-observation models only (closures of the README's form)")
+        raise ValueError("r_seed / r_stream: the scalar Gaussian-observation models only (closures of the README's form)")
     rf_dev = "multinomial_r" if rf == "multinomial" else rf      # Rcpp::sample's own algorithm on R's unif_rand() stream
     if ctl.get("draws") is not None:
-        raise ValueError("r_seed and draws are mutually exclusive")
+        raise ValueError("r_seed / r_stream and draws are mutually exclusive")
     T = int(np.asarray(y).size)
     dec = np.ones(T, dtype=bool) if ra != "SIS" else np.zeros(T, dtype=bool)
+    if guess is not None and ra == "SISAR" and len(guess) == T:
+        dec = np.asarray(guess, dtype=bool).copy()
     ctl = {k: v for k, v in ctl.items() if k not in ("seed", "stream", "draws")}
-    for _ in range(T + 1):
-        d = r_seeded_draws(r_seed, T, int(N), rf, dec, obs_times)
+    start = g.snapshot()
+    upto_draw = None
+    for _ in range(T + 2):
+        g.restore(start)
+        d = r_stream_draws(g, T, int(N), rf, dec, obs_times, upto=upto_draw)
         res = particle_filter_core(y, N, model, theta, "BPF", obs_times, ra, rf_dev, threshold, return_particles, draws=d, **ctl)
         got = np.asarray(res["_extras"]["resampled"], dtype=bool)
         early = res["_extras"]["early_return_step"]
         upto = (early - 1) if early else T                    # after a degenerate early return nothing more is drawn
         if np.array_equal(got[:upto], dec[:upto]):
+            if early and upto_draw != early:                  # (one more round so that the generator stops where R's does)
+                upto_draw = early
+                continue
             res["_extras"]["r_seed_decisions"] = dec[:upto].copy()
             return res
+        upto_draw = None
         k = int(np.flatnonzero(got[:upto] != dec[:upto])[0])  # everything before the first disagreement was drawn right
         dec[:k + 1] = got[:k + 1]
         dec[k + 1:] = got[k + 1:]

@@ -142,7 +142,23 @@ def readme_series(seed=1405, t_val=20, phi=0.8, sigma_x=1.0, sigma_y=0.5):
 
 
 def _qnorm_vec(p):
-    return np.array([qnorm(float(v)) for v in p], dtype=np.float64)
+    """qnorm of a vector: the central region (|p - 0.5| <= 0.425, 85 % of the draws) vectorised with the same expression as
+    `qnorm`, the tails through `qnorm` itself (their log / sqrt are libm's, as in R)."""
+    p = np.asarray(p, dtype=np.float64)
+    q = p - 0.5
+    out = np.empty_like(p)
+    c = np.abs(q) <= 0.425
+    r = 0.180625 - q[c] * q[c]
+    out[c] = q[c] * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r
+                         + 45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r
+                      + 133.14166789178437745) * r + 3.387132872796366608) / \
+        (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r
+             + 21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r
+          + 42.313330701600911252) * r + 1.0)
+    t = ~c
+    if t.any():
+        out[t] = [qnorm(float(v)) for v in p[t]]
+    return out
 
 
 def rnorm_vec(g, n):
@@ -150,6 +166,57 @@ def rnorm_vec(g, n):
     u = g.runif(2 * int(n))
     v = np.floor(_BIG * u[0::2]) + u[1::2]
     return _qnorm_vec(v / _BIG)
+
+
+def sample_int_large(g, n, size):
+    """sample.int(n, size) without replacement for n > 1e7 and size <= n / 2 -- e.g. the reference's chain seeds,
+    `sample.int(.Machine$integer.max, num_chains)` (R/pmmh.R:511).  R (>= 3.6, sample.kind = "Rejection") takes the hashing version
+    there (do_sample2): per element R_unif_index(n) + 1, redrawn on a duplicate; R_unif_index draws bits = ceil(log2(n)) random bits
+    -- rbits: v = 65536 v + floor(unif_rand() * 65536) for 0, 16, ... <= bits, masked to `bits` bits -- and rejects v >= n.
+    Restated from R's documented algorithm (src/main/RNG.c, src/main/unique.c; third party, absent from /root/reference); checked
+    end to end by the README replay (tests/test_readme_r_stream.py)."""
+    n, size = int(n), int(size)
+    if not (n > 10_000_000 and size <= n // 2):
+        raise ValueError("sample_int_large: only R's hashing case (n > 1e7, size <= n / 2)")
+    bits = int(math.ceil(math.log2(n)))
+    out = []
+    while len(out) < size:
+        while True:
+            v = 0
+            for _ in range(0, bits + 1, 16):
+                v = 65536 * v + int(math.floor(g.unif_rand() * 65536))
+            v &= (1 << bits) - 1
+            if v < n:
+                break
+        if v + 1 not in out:
+            out.append(v + 1)
+    return out
+
+
+def r_stream_draws(g, T, N, resample_fn, resampled, obs_times=None, upto=None):
+    """The draws R makes inside ONE `bootstrap_filter()` call from the generator's CURRENT position (closures of the README's form,
+    see r_seeded_draws): `g` is advanced by exactly what R consumes.  `upto`: the run returned early at that observation (degenerate
+    weights, R/particle_filter_core.R:189-202) -- nothing is drawn after it."""
+    z_init = rnorm_vec(g, N)
+    z_trans, u_res = [], []
+    prev = 0
+    last = T if upto is None else int(upto)
+    for i in range(last):
+        ot = int(obs_times[i]) if obs_times is not None else i + 1
+        for _ in range(ot - prev):
+            z_trans.append(rnorm_vec(g, N))
+        prev = ot
+        if resampled[i] and not (upto is not None and i == last - 1):
+            u_res.append(g.runif(N) if resample_fn != "systematic" else np.array([g.unif_rand()]))
+    nu = N if resample_fn != "systematic" else 1
+    n_trans = (int(obs_times[T - 1]) if obs_times is not None else T) if T > 0 else 0
+    zt = np.zeros((max(n_trans, 1), N))
+    if z_trans:
+        zt[:len(z_trans)] = np.array(z_trans).reshape(-1, N)
+    ur = np.array(u_res).reshape(-1, nu) if u_res else np.zeros((0, nu))
+    pad = np.zeros((max(T - ur.shape[0], 1 if ur.shape[0] == 0 else 0), nu))     # (the filter indexes u_res by resample CALL)
+    full = np.vstack([ur, pad])
+    return {"z_init": z_init, "z_trans": zt, "u_res": full if nu > 1 else full.reshape(-1)}
 
 
 def r_seeded_draws(seed, T, N, resample_fn, resampled, obs_times=None):
@@ -160,20 +227,4 @@ def r_seeded_draws(seed, T, N, resample_fn, resampled, obs_times=None):
         Rcpp::runif(N) (stratified), R::runif(1) (systematic) or the N unif_rand() calls of Rcpp::sample (multinomial).
     `resampled[i]` says whether observation i+1 resamples (it decides whether uniforms are consumed there).
     Returns the `draws` dict of the filters' parity mode."""
-    g = RRandom(seed)
-    z_init = rnorm_vec(g, N)
-    z_trans, u_res = [], []
-    prev = 0
-    for i in range(T):
-        ot = int(obs_times[i]) if obs_times is not None else i + 1
-        for _ in range(ot - prev):
-            z_trans.append(rnorm_vec(g, N))
-        prev = ot
-        if resampled[i]:
-            u_res.append(g.runif(N) if resample_fn != "systematic" else np.array([g.unif_rand()]))
-    nu = N if resample_fn != "systematic" else 1
-    zt = np.array(z_trans).reshape(-1, N) if z_trans else np.zeros((1, N))
-    ur = np.array(u_res).reshape(-1, nu) if u_res else np.zeros((1, nu))
-    # the filter indexes u_res by resample CALL, and pads to the maximum number of calls
-    pad = np.zeros((max(T - ur.shape[0], 0), nu))
-    return {"z_init": z_init, "z_trans": zt, "u_res": np.vstack([ur, pad]) if nu > 1 else np.concatenate([ur.reshape(-1), pad.reshape(-1)])}
+    return r_stream_draws(RRandom(seed), T, N, resample_fn, resampled, obs_times)

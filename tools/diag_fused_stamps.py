@@ -61,6 +61,7 @@ for k in (2, 3, 4, 5, 6, 7):
 print("   links %d" % r[8])
 
 r2 = np.array(list(st)).reshape(4, 16)[2]
+print("   compose split: loads + pre %d, compose 1 %d, compose 2 %d, collect + encode + publish %d" % (r2[5] - r2[13], r2[6] - r2[5], r2[7] - r2[6], r2[14] - r2[7]))
 print("crossing block (B/4), P pass: boundaries %d; block_scan %d, tail entry %d, minmax2 %d, compose %d, barrier %d, to the end %d" % (
     r2[8], r2[11] - r2[10], r2[12] - r2[11], r2[3] - r2[12], r2[14] - r2[13], r2[15] - r2[14], r2[9] - r2[15]))
 
@@ -76,3 +77,27 @@ late = np.argsort(e)[::-1][:12]
 print("end of expansion (10 ns ticks after the earliest P publish): median %d, p90 %d, max %d; latest blocks: %s" % (
     np.median(e) - p[2][:Bn].min(), np.percentile(e, 90) - p[2][:Bn].min(), e.max() - p[2][:Bn].min(),
     ", ".join("%d (+%d)" % (int(b), e[b] - p[2][:Bn].min()) for b in late)))
+
+# ---- the whole grid's time line (wall clock, 10 ns ticks after the first block's first instruction) ----
+lib.bssm_ctx_fused_waket.argtypes = [C.c_void_p, C.c_void_p]
+wt = (C.c_longlong * 1536)()
+_lib.check(lib.bssm_ctx_fused_waket(cx.handle, wt))
+wk = np.array(list(wt)).reshape(3, 512)[:, :Bn]
+z = st0.min()
+def q(a): return "min %4d  median %4d  p90 %4d  max %4d" % (a.min() - z, np.median(a) - z, np.percentile(a, 90) - z, a.max() - z)
+print("time line of all %d blocks (10 ns ticks after the first start)" % Bn)
+print("   start                 " + q(st0))
+print("   partials published    " + q(p[0][:Bn]))
+print("   R gathered partials   %4d" % (p[3][8] - z))
+print("   got slot 1            " + q(wk[0]))
+print("   W record published    " + q(p[1][:Bn]))
+print("   R gathered W          %4d" % (p[3][9] - z))
+print("   got total             " + q(wk[1]))
+print("   P record published    " + q(p[2][:Bn]))
+print("   R gathered P          %4d" % (p[3][10] - z))
+print("   got state             " + q(wk[2]))
+print("   expansion done        " + q(e))
+for nm, a, b in (("phase A + partials (start -> publish)", st0, p[0][:Bn]), ("weights + W scan (slot 1 -> publish)", wk[0], p[1][:Bn]),
+                 ("P scan (total -> publish)", wk[1], p[2][:Bn]), ("expansion (state -> end)", wk[2], e)):
+    d = b - a
+    print("   %-40s median %4d  p90 %4d  max %4d (block %d)" % (nm, np.median(d), np.percentile(d, 90), d.max(), int(d.argmax())))
