@@ -253,6 +253,7 @@ def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
                                         resample_algorithm, resample_fn, threshold, return_particles, **extra, **kwargs)
     r_seed = kwargs.pop("r_seed", None)
     r_stream = kwargs.pop("r_stream", None)          # an rrng.RRandom positioned where R's generator stands before this call
+    r_guess = kwargs.pop("r_guess", None)            # first guess of the resample decisions (any guess converges; a good one saves rounds)
     ctl = {k: kwargs.pop(k) for k in ("seed", "stream", "draws", "ctx", "return_ancestors") if k in kwargs}
     model = models.resolve(init_fn, transition_fn, log_likelihood_fn)
     if model == "lgmv":                      # multivariate linear-Gaussian family: the descriptor packs its matrices for this parameter draw
@@ -265,7 +266,7 @@ def bootstrap_filter(y, num_particles, init_fn, transition_fn, log_likelihood_fn
             raise ValueError("r_seed and r_stream are mutually exclusive")
         from .rrng import RRandom
         return _r_seeded_bootstrap(y, num_particles, model, theta, obs_times, resample_algorithm, resample_fn, threshold,
-                                   return_particles, RRandom(int(r_seed)) if r_seed is not None else r_stream, ctl)
+                                   return_particles, RRandom(int(r_seed)) if r_seed is not None else r_stream, ctl, r_guess)
     return particle_filter_core(y, num_particles, model, theta, "BPF", obs_times, resample_algorithm, resample_fn,
                                 threshold, return_particles, **ctl)
 

@@ -412,7 +412,33 @@ def _mvrnorm(mu, sigma, z):
     return np.asarray(mu) + (vec * np.sqrt(np.maximum(ev, 0.0))) @ np.asarray(z)
 
 
-def run_chain_host(pf, m, init_theta, proposal_cov, transform, priors, rng, return_latent_state_est=False):
+def _mvrnorm_lapack(mu, sigma, z):
+    """MASS::mvrnorm(1, mu, Sigma) with eigen()'s OWN eigenvectors: LAPACK dsyevr as R's La_rs calls it (jobz V, range A, lower
+    triangle), eigenvalues reversed into decreasing order, signs as LAPACK leaves them.  The sign of an eigenvector does not
+    change the proposal's law (z is symmetric), but it decides WHICH proposal a given z becomes -- the R-stream replay needs R's."""
+    from scipy.linalg import eigh
+    ev, vec = eigh(np.asarray(sigma, dtype=np.float64), lower=True, driver="evr")
+    ev, vec = ev[::-1], vec[:, ::-1]
+    if not np.all(ev >= -1e-6 * abs(ev[0])):
+        raise ValueError("'Sigma' is not positive definite")
+    return np.asarray(mu) + vec @ (np.sqrt(np.maximum(ev, 0.0)) * np.asarray(z))
+
+
+class _RStreamRng:
+    """numpy-Generator-shaped view of an rrng.RRandom: standard_normal(p) = rnorm(p), random() = runif(1), in R's stream."""
+
+    def __init__(self, g):
+        self.g = g
+
+    def standard_normal(self, p):
+        from .rrng import rnorm_vec
+        return rnorm_vec(self.g, int(p))
+
+    def random(self):
+        return self.g.unif_rand()
+
+
+def run_chain_host(pf, m, init_theta, proposal_cov, transform, priors, rng, return_latent_state_est=False, mvrnorm=None):
     """chain_result's loop (R/pmmh.R:403-415,422-500) on the host, for models given as closures: `pf(theta)` runs one
     filter (closure mode: the model on the host, the core's work on the device) and returns its result list; `priors` are
     callables; proposal / acceptance draws come from `rng`."""
@@ -428,7 +454,7 @@ def run_chain_host(pf, m, init_theta, proposal_cov, transform, priors, rng, retu
     theta_chain[0], se_chain[0] = cur, cur_se
     accepted = 0
     for i in range(1, m):                                                                                      # :422
-        prop = _back_transform(_mvrnorm(_transform(cur, transform), cov_trans, rng.standard_normal(p)), transform)   # :424-432
+        prop = _back_transform((mvrnorm or _mvrnorm)(_transform(cur, transform), cov_trans, rng.standard_normal(p)), transform)   # :424-432
         lp_prop = np.array([pr(v) for pr, v in zip(priors, prop)])
         if not np.all(np.isfinite(lp_prop)):                                                                   # :435-442
             theta_chain[i], se_chain[i] = cur, cur_se
@@ -574,6 +600,82 @@ def _pmmh_closures(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, 
     return result
 
 
+def _pmmh_r_stream(y, m, init_fn, transition_fn, log_likelihood_fn, prior_names, priors, transform, pilot_init_params, burn_in,
+                   num_chains, obs_times, tune_control, verbose, return_latent_state_est, seed, owner, kwargs):
+    """pmmh(..., seed = s, r_stream = True): the call as R executes it after `set.seed(s)` -- ONE generator (rrng.RRandom, R's
+    Mersenne-Twister + inversion) consumed in the reference's order:
+        seeds <- sample.int(.Machine$integer.max, num_chains)                R/pmmh.R:511
+        per chain: set.seed(seeds[c]) :346; .run_pilot_chain (rnorm(p, 0, proposal_sd) until the priors are finite, one filter,
+        log(runif(1)); .pilot_run) R/pmmh_tuning.R:111-317; the main loop :422-500 (MASS::mvrnorm on eigen()'s vectors, one filter,
+        log(runif(1)))
+    and inside every filter run rnorm(N), rnorm(N) per transition and Rcpp::runif(N) where the filter resamples
+    (bootstrap_filter(r_stream = g): the device runs the filter on those draws).  Chains run one after the other, as with the
+    reference's num_cores = 1.  The scalar Gaussian-observation models only (closures of the README's form), bootstrap filter,
+    wrapper defaults in the main chain (SISAR, stratified) and tune_control's pilot_resample_* in the pilot, as the reference.
+    With the README's arguments this prints the README's table (README.md:197-208) -- tests/test_gpu_readme_r_stream.py."""
+    from .rrng import RRandom, sample_int_large
+    ctx = kwargs.pop("ctx", None)
+    print_result = bool(kwargs.pop("print_result", True))
+    for k in ("batch_chains", "chains_per_gpu", "lockstep_large", "pf_resample_algorithm", "pf_resample_fn"):
+        kwargs.pop(k, None)
+    if seed is None:
+        raise ValueError("r_stream needs a seed (the argument of set.seed)")
+    g = RRandom(int(seed))                                                                   # set.seed(seed)            :255-256
+    seeds = sample_int_large(g, 2147483647, num_chains)                                       # :511
+    rng = _RStreamRng(g)
+    p = len(prior_names)
+    m_, chains, extras = int(m), [], {}
+    last_dec = {}
+
+    def pf(theta, n, ra, rf):
+        th = {k: float(v) for k, v in zip(prior_names, theta)}
+        r = bootstrap_filter(y, int(n), init_fn, transition_fn, log_likelihood_fn, obs_times=obs_times, resample_algorithm=ra,
+                             resample_fn=rf, return_particles=False, r_stream=g, r_guess=last_dec.get((int(n), ra)),
+                             **({"ctx": ctx} if ctx is not None else {}), **th)
+        last_dec[(int(n), ra)] = r["_extras"].get("r_seed_decisions")      # (first guess of the next run's resample decisions: fewer rounds)
+        return r
+
+    for c in range(num_chains):
+        g.set_seed(seeds[c])                                                                  # :346
+        print("Running chain %d..." % (c + 1))                                                # message(), unconditional (:347-353)
+        print("Running pilot chain for tuning...")
+        init_theta = [float(pilot_init_params[c][k]) for k in prior_names]
+        p_ra, p_rf = tune_control["pilot_resample_algorithm"], tune_control["pilot_resample_fn"]
+        pilot = run_pilot_chain(lambda th, n, tag: pf(th, n, p_ra, p_rf)["loglike"], tune_control["pilot_m"], tune_control["pilot_n"],
+                                tune_control["pilot_reps"], priors, tune_control["pilot_proposal_sd"], transform, init_theta, rng, verbose,
+                                message=(print if verbose else (lambda *_: None)))
+        print("Running Particle MCMC chain with tuned settings...")                           # :395
+        out = run_chain_host(lambda th: pf(th, pilot["target_n"], "SISAR", "stratified"), m_, pilot["pilot_theta_mean"],
+                             pilot["pilot_theta_cov"], transform, priors, rng, return_latent_state_est, mvrnorm=_mvrnorm_lapack)
+        out["pilot"] = pilot
+        chains.append(out["theta_chain"])
+        extras[c] = out
+    chains = np.array(chains)                                                                 # (num_chains, m, p)
+    post = chains[:, burn_in:, :]
+    diag_ess, diag_rhat = {}, {}
+    for j, name in enumerate(prior_names):
+        mat = post[:, :, j].T
+        diag_ess[name] = diagnostics.ess(mat) if num_chains > 1 else float("nan")
+        diag_rhat[name] = diagnostics.rhat(mat)
+    result = diagnostics.PmmhOutput({
+        "theta_chain": {"chain": np.repeat(np.arange(1, num_chains + 1), m_ - burn_in),
+                        **{name: post[:, :, j].reshape(-1) for j, name in enumerate(prior_names)}},
+        "diagnostics": {"ess": diag_ess, "rhat": diag_rhat},
+        "_extras": {"local_chains": extras, "seeds": np.array(seeds), "rank": 0, "world_size": 1, "r_stream": True},
+    })
+    if return_latent_state_est:
+        result["latent_state_chain"] = {c: extras[c]["state_est_chain"][burn_in:] for c in range(num_chains)}
+    if print_result:
+        print(result.format())
+    if any(np.isfinite(v) and v < 400 for v in diag_ess.values()):
+        warnings.warn("Some ESS values are below 400, indicating poor mixing. "
+                      "Consider running the chains for more iterations.")
+    if any(np.isfinite(v) and v > 1.01 for v in diag_rhat.values()):
+        warnings.warn("\nSome Rhat values are above 1.01, indicating that the chains have not converged. \n"
+                      "Consider running the chains for more iterations and/or increase burn_in.")
+    return result
+
+
 def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors, pilot_init_params, burn_in,
          num_chains=4, obs_times=None, resample_algorithm=None, resample_fn=None, param_transform=None,
          tune_control=None, verbose=False, return_latent_state_est=False, seed=None, num_cores=1,
@@ -657,6 +759,11 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     # per-chain seeds drawn up-front, so results do not depend on how chains are placed (R/pmmh.R:511)
     seeds = np.random.default_rng(seed).integers(1, 2 ** 31 - 1, size=num_chains)
 
+    if kwargs.pop("r_stream", False):
+        if not use_pilot or _chain_runner is not None or pf_wrapper is not bootstrap_filter:
+            raise ValueError("r_stream: bootstrap_filter with the reference's own pilot tuning (no num_particles / proposal_cov overrides)")
+        return _pmmh_r_stream(y, m, init_fn, transition_fn, log_likelihood_fn, prior_names, priors, transform, pilot_init_params, burn_in,
+                              num_chains, obs_times, tune_control, verbose, return_latent_state_est, seed, owner, kwargs)
     dist = None
     try:
         import torch.distributed as tdist

@@ -43,25 +43,6 @@ README_TABLE = {            # README.md:204-208
 README_TARGET_N = (50, 50)  # README.md:197,202
 
 
-# ---- vectorised AS 241 (R's qnorm5), same formulas as rrng.qnorm ------------------------------------------------------
-def _qnorm(p):
-    p = np.asarray(p, dtype=np.float64)
-    q = p - 0.5
-    out = np.empty_like(p)
-    c = np.abs(q) <= 0.425
-    r = 0.180625 - q[c] * q[c]
-    out[c] = q[c] * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r
-                         + 45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r
-                      + 133.14166789178437745) * r + 3.387132872796366608) / \
-        (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r
-             + 21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r
-          + 42.313330701600911252) * r + 1.0)
-    t = ~c
-    if t.any():
-        out[t] = [rrng.qnorm(float(v)) for v in p[t]]          # tails: the scalar routine (log / sqrt of libm, as R)
-    return out
-
-
 class R:
     """R's session generator."""
 
@@ -78,27 +59,11 @@ class R:
         return self.g.runif(n)
 
     def rnorm(self, n, mean=0.0, sd=1.0):
-        u = self.g.runif(2 * int(n))
-        z = _qnorm((np.floor(134217728.0 * u[0::2]) + u[1::2]) / 134217728.0)        # snorm.c INVERSION
-        return mean + sd * z                                                          # rnorm: mu + sigma * norm_rand()
+        return mean + sd * rrng.rnorm_vec(self.g, n)                                  # rnorm: mu + sigma * norm_rand()  (snorm.c INVERSION)
 
     def sample_int_max(self, size):
-        """sample.int(.Machine$integer.max, size): n > 1e7 and size <= n / 2 -> the hashing version (do_sample2): per element
-        R_unif_index(n) + 1, redrawn on a duplicate.  R_unif_index (sample.kind = "Rejection"): bits = ceil(log2(n)) = 31;
-        rbits draws floor(unif_rand() * 65536) for n = 0, 16 (two draws), v = 65536 v + v1, masked to 31 bits; rejected while >= n."""
-        n = 2147483647
-        out = []
-        while len(out) < size:
-            while True:
-                v = 0
-                for _ in range(2):
-                    v = 65536 * v + int(math.floor(self.g.unif_rand() * 65536))
-                v &= (1 << 31) - 1
-                if v < n:
-                    break
-            if v + 1 not in out:
-                out.append(v + 1)
-        return out
+        """sample.int(.Machine$integer.max, size) -- rrng.sample_int_large (R's hashing version on the rejection sampler)"""
+        return rrng.sample_int_large(self.g, 2147483647, size)
 
 
 def rsum(x):
@@ -116,41 +81,48 @@ def dnorm_log(y, mu, sigma):
     return -(M_LN_SQRT_2PI + 0.5 * x * x + math.log(sigma))
 
 
-def resample_stratified(r, w):
-    """src/resampling.cpp:16-40"""
-    n = len(w)
-    prob = w / seqsum(w)
-    cum = np.cumsum(prob)
-    us = (np.arange(n, dtype=np.float64) + r.runif(n)) / n
-    idx = np.empty(n, dtype=np.int64)
-    j = 0
-    for i in range(n):
-        while j < n - 1 and cum[j] < us[i]:
-            j += 1
-        idx[i] = j
-    return idx
-
-
-def bootstrap_filter(r, y, N, phi, sigma_x, sigma_y, counters=None):
+def bootstrap_filter(r, y, N, phi, sigma_x, sigma_y, record=None):
     """bootstrap_filter(y, N, init_fn, transition_fn, log_likelihood_fn, phi, sigma_x, sigma_y) with the README's closures and the
-    wrapper's defaults (SISAR, stratified, threshold N / 2): the log-likelihood (R/particle_filter_core.R:204-224)."""
-    x = r.rnorm(N, 0.0, 1.0)
+    wrapper's defaults (SISAR, stratified, threshold N / 2): the log-likelihood (R/particle_filter_core.R:204-224).
+    `record` (a list): this run's parameters, standard-normal / uniform draws, decisions and result are appended."""
+    z0 = r.rnorm(N)
+    x = 0.0 + 1.0 * z0                                       # rnorm(N, mean = 0, sd = 1)
     loglike = 0.0
+    zs, us, dec, hist = [], [], [], []
     for yi in y:
-        x = phi * x + np.sin(x) + r.rnorm(N, 0.0, sigma_x)
+        z = r.rnorm(N)
+        zs.append(z)
+        x = phi * x + np.sin(x) + (0.0 + sigma_x * z)        # ... + rnorm(N, mean = 0, sd = sigma_x)
         lw = dnorm_log(yi, x, sigma_y)
         if np.all(lw < -1e8):
-            return -math.inf
+            loglike = -math.inf
+            break
         mx = lw.max()
         un = np.exp(lw - mx)
         ws = rsum(un)
         w = un / ws
         loglike = loglike + (mx + math.log(ws) - math.log(N))
+        hist.append(loglike)
         ess = 1.0 / rsum(w * w)
-        if ess < N / 2:
-            x = x[resample_stratified(r, w)]
-            if counters is not None:
-                counters["resamplings"] += 1
+        dec.append(bool(ess < N / 2))
+        if dec[-1]:
+            n = len(w)
+            prob = w / seqsum(w)                             # src/resampling.cpp:16-40
+            cum = np.cumsum(prob)
+            u = r.runif(n)
+            us.append(u)
+            ut = (np.arange(n, dtype=np.float64) + u) / n
+            idx = np.empty(n, dtype=np.int64)
+            j = 0
+            for i in range(n):
+                while j < n - 1 and cum[j] < ut[i]:
+                    j += 1
+                idx[i] = j
+            x = x[idx]
+    if record is not None:
+        record.append({"theta": (float(phi), float(sigma_x), float(sigma_y)), "N": int(N), "z_init": z0, "z_trans": np.array(zs),
+                       "u_res": np.array(us).reshape(-1, N), "resampled": np.array(dec, dtype=bool), "loglike": loglike,
+                       "loglike_history": np.array(hist)})
     return loglike
 
 
@@ -193,16 +165,16 @@ def mvrnorm1(r, mu, Sigma):
     if not np.all(ev >= -1e-6 * abs(ev[0])):
         raise ValueError("'Sigma' is not positive definite")
     z = r.rnorm(len(mu))
-    return mu + V @ (np.sqrt(np.maximum(ev, 0.0)) * z)
+    return mu + V @ (np.sqrt(np.maximum(ev, 0.0)) * z), z
 
 
-def run_chain(r, y, seed, init, m, pilot_m, pilot_n=100, pilot_reps=100, proposal_sd=0.5, log=None):
+def run_chain(r, y, seed, init, m, pilot_m, pilot_n=100, pilot_reps=100, proposal_sd=0.5, log=None, record=None, main=None):
     r.set_seed(seed)
     # ---- .run_pilot_chain ----
     cur = np.array(init, dtype=np.float64)
     chain = np.empty((pilot_m, 3))
     chain[0] = cur
-    cur_ll = bootstrap_filter(r, y, pilot_n, *cur)
+    cur_ll = bootstrap_filter(r, y, pilot_n, *cur, record=record)
     for k in range(1, pilot_m):
         while True:
             prop = cur + r.rnorm(3, 0.0, proposal_sd)
@@ -210,7 +182,7 @@ def run_chain(r, y, seed, init, m, pilot_m, pilot_n=100, pilot_reps=100, proposa
             if np.all(np.isfinite(lp_prop)):
                 break
         lp_cur = log_priors(cur)
-        prop_ll = bootstrap_filter(r, y, pilot_n, *prop)
+        prop_ll = bootstrap_filter(r, y, pilot_n, *prop, record=record)
         num = rsum(lp_prop) + prop_ll + 0.0
         den = rsum(lp_cur) + cur_ll + 0.0
         ratio = num - den
@@ -223,7 +195,7 @@ def run_chain(r, y, seed, init, m, pilot_m, pilot_n=100, pilot_reps=100, proposa
     mean = r_mean_cols(post)
     cov = r_cov(post)
     # ---- .pilot_run ----
-    lls = np.array([bootstrap_filter(r, y, pilot_n, *mean) for _ in range(pilot_reps)])
+    lls = np.array([bootstrap_filter(r, y, pilot_n, *mean, record=record) for _ in range(pilot_reps)])
     var = r_cov(lls.reshape(-1, 1))[0, 0]
     target_n = int(min(max(math.ceil(pilot_n * var), 50), 1000))
     if log is not None:
@@ -231,36 +203,42 @@ def run_chain(r, y, seed, init, m, pilot_m, pilot_n=100, pilot_reps=100, proposa
     # ---- main chain ----
     cur = mean.copy()
     theta = np.empty((m, 3))
-    cur_ll = bootstrap_filter(r, y, target_n, *cur)
+    cur_ll = bootstrap_filter(r, y, target_n, *cur, record=record)
     theta[0] = cur
     acc = 0
+    zp, ua, lls_main = np.zeros((m, 3)), np.zeros(m), [cur_ll]
     for i in range(1, m):
-        prop = mvrnorm1(r, cur, cov)
+        prop, zp[i] = mvrnorm1(r, cur, cov)
         lp_prop = log_priors(prop)
         if not np.all(np.isfinite(lp_prop)):
             theta[i] = cur
             continue
-        prop_ll = bootstrap_filter(r, y, target_n, *prop)
+        prop_ll = bootstrap_filter(r, y, target_n, *prop, record=record)
+        lls_main.append(prop_ll)
         num = prop_ll + rsum(lp_prop) + 0.0
         den = cur_ll + rsum(log_priors(cur)) + 0.0
         ratio = num - den
         if math.isnan(ratio):
             ratio = -math.inf
-        if math.log(r.runif1()) < ratio:
+        ua[i] = r.runif1()
+        if math.log(ua[i]) < ratio:
             cur, cur_ll = prop, prop_ll
             acc += 1
         theta[i] = cur
+    if main is not None:
+        main.append({"init_theta": mean, "proposal_cov": cov, "target_n": target_n, "z_prop": zp, "u_accept": ua, "theta_chain": theta,
+                     "filter_logliks": np.array(lls_main), "accepted": acc})
     return theta, target_n, acc
 
 
-def replay(seed=1405, m=500, burn_in=50, pilot_m=200, verbose=True):
+def replay(seed=1405, m=500, burn_in=50, pilot_m=200, verbose=True, record=None, main=None):
     _, y = rrng.readme_series(seed)                      # README.md:97-114 (its own set.seed(1405) block)
     r = R(seed)                                          # pmmh(): set.seed(seed)
     seeds = r.sample_int_max(2)
     inits = [(0.4, 0.4, 0.4), (0.8, 0.8, 0.8)]
     log, chains, targets = [], [], []
     for c in range(2):
-        th, tn, acc = run_chain(r, y, seeds[c], inits[c], m, pilot_m, log=log)
+        th, tn, acc = run_chain(r, y, seeds[c], inits[c], m, pilot_m, log=log, record=record, main=main)
         chains.append(th[burn_in:])
         targets.append(tn)
         log.append("chain %d: seed %d, accepted %d of %d" % (c + 1, seeds[c], acc, m - 1))
@@ -272,6 +250,7 @@ def replay(seed=1405, m=500, burn_in=50, pilot_m=200, verbose=True):
     if verbose:
         print("\n".join(log))
         print(out.format())
+    out["_extras"] = {"seeds": seeds, "y": y}
     return out, targets
 
 
