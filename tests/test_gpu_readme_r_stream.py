@@ -77,3 +77,27 @@ def test_device_filter_on_the_replays_own_runs(B, oracle):
         err = np.max(np.abs(np.asarray(r["loglike_history"]) - rec["loglike_history"]) / np.maximum(1.0, np.abs(rec["loglike_history"])))
         worst = max(worst, float(err))
     assert worst < 1e-9, worst
+
+
+def test_reference_seeded_filter_test_in_r_stream(B):
+    """tests/testthat/test-bootstrap_filter.R:149-207 as R runs it: set.seed(1405), the test's own simulate_ssm (rnorm(1, ...) calls), then
+    bootstrap_filter(N = 100, SISAR, systematic) -- all from ONE R stream; the reference asserts length(state_est) == length(x) and
+    rmse(state_est, x) < 0.5.  Here the filter runs on the device from the generator's position after the simulation."""
+    import math
+    g = B.rrng.RRandom(1405)
+    phi, sx, sy, T = 0.8, 1.0, 0.5, 50
+    rnorm1 = lambda mean, sd: mean + sd * g.norm_rand()       # noqa: E731
+    init_state = rnorm1(0.0, sx)
+    x, y = np.zeros(T), np.zeros(T)
+    x[0] = phi * init_state + math.sin(init_state) + rnorm1(0.0, sx)
+    y[0] = x[0] + rnorm1(0.0, sy)
+    for t in range(1, T):
+        x[t] = phi * x[t - 1] + math.sin(x[t - 1]) + rnorm1(0.0, sx)
+        y[t] = x[t] + rnorm1(0.0, sy)
+    xs = np.concatenate([[init_state], x])
+    mdl = B.models.ar1_sin()
+    res = B.bootstrap_filter(y, 100, mdl.init_fn, mdl.transition_fn, mdl.log_likelihood_fn, resample_algorithm="SISAR",
+                             resample_fn="systematic", r_stream=g, phi=phi, sigma_x=sx, sigma_y=sy)
+    assert len(res["state_est"]) == len(xs)
+    rmse = float(np.sqrt(np.mean((np.asarray(res["state_est"]) - xs) ** 2)))
+    assert rmse < 0.5, rmse
