@@ -5,13 +5,25 @@
  * executed by the product (bayesssm_amd/); only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg use it, and only as the checker / baseline.
  *
- * PARITY STATUS: "parity unpinned" for log-likelihood values, seeded ancestor
- * vectors and multinomial draws.  The reference (R + Rcpp) cannot be built or
- * run in this environment (no R, no Rcpp headers) and its own test-suite holds
- * no numeric golden vectors for the filter.  What IS pinned:
- * the RNG-independent known-answer checks of tests/testthat/test-resampling.R
- * (:2-28, :48-68, :190-202) which tests/test_oracle_golden.py re-expresses
- * against this file, plus hand-derived small cases in tests/golden/.
+ * PARITY STATUS (round 3): PINNED BY AN OUTPUT OF THE REFERENCE for the bootstrap
+ * filter on the scalar Gaussian-observation models (SISAR + stratified) and for
+ * the PMMH loop: the reference's README prints the result of its example
+ * pmmh(..., seed = 1405) call (README.md:196-208; tests/golden/readme_pmmh_table.json).
+ * tests/harness/readme_r_stream.py replays that call in R's own random stream and
+ * prints the README's lines digit for digit; tests/test_readme_r_stream.py holds
+ * orc_pf_run to that replay on each of the call's 1 439 filter runs (log-likelihood
+ * after every observation within 1e-12, identical resample decisions) and
+ * orc_pmmh_chain on both main chains (identical theta chains).
+ * Also pinned: the RNG-independent known-answer checks of
+ * tests/testthat/test-resampling.R (:2-28, :48-68, :190-202) which
+ * tests/test_oracle_golden.py re-expresses against this file, plus hand-derived
+ * small cases in tests/golden/.
+ * Still "parity unpinned" (nothing in /root/reference holds a number for them; the
+ * reference -- R + Rcpp -- cannot be built or run here): whole-run values of the
+ * auxiliary and resample-move filters, the SIR model, the multivariate family
+ * (tied to the scalar path bit for bit at d = p = 1 and to the Kalman filter),
+ * the systematic resampler inside a seeded whole run, and the multinomial stream
+ * (follows Rcpp::sample's published algorithm; never compared with a run of R).
  *
  * Every function cites the reference file:line it follows (paths relative to
  * the reference checkout).  Arithmetic follows the reference operation by

@@ -2,8 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg -- never by the product package `bayesssm_amd`.
-Parity status: see the header of bssm_oracle.c ("parity unpinned" for
-log-likelihood values / seeded ancestors / multinomial draws).
+Parity status: see the header of bssm_oracle.c (round 3: the bootstrap filter and the PMMH loop are pinned by the
+reference's printed README output, tests/test_readme_r_stream.py; APF / RMPF / SIR / multivariate whole-run values and the
+multinomial stream remain "parity unpinned").
 """
 import ctypes as C
 import os
