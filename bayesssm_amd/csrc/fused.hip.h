@@ -388,16 +388,25 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
 #pragma unroll
         for (int k = 0; k < EL; k++) x8[k] = (j0 + k < N) ? g.xin[j0 + k] : 0.0;
     }
+    // the transition normals first: the generator needs nothing from memory, so its ~1 200 vector instructions run while the particle and
+    // run-state loads above are in flight (the early exit below is the first thing that needs a loaded value)
+    double z8[EL];
+#pragma unroll
+    for (int i = 0; i < EL / 2; i++) {
+        const long long j = j0 + 2 * i;
+        z8[2 * i] = 0.0; z8[2 * i + 1] = 0.0;
+        if (g.trans && j < N) {
+            if (g.ns.arr) { if (j + 1 < N) { const double2 q = *reinterpret_cast<const double2*>(g.ns.arr + j); z8[2 * i] = q.x; z8[2 * i + 1] = q.y; } else { z8[2 * i] = g.ns.arr[j]; } }
+            else normal_pair(g.ns.key, g.ns.purpose, g.ns.call, 0, (uint32_t)(j >> 1), z8[2 * i], z8[2 * i + 1]);
+        }
+    }
     if (s_dead || s_flags) return;
 #pragma unroll
     for (int i = 0; i < EL / 2; i++) {
         const long long j = j0 + 2 * i;
         if (g.trans && j < N) {
-            double z0, z1;
-            if (g.ns.arr) { if (j + 1 < N) { const double2 q = *reinterpret_cast<const double2*>(g.ns.arr + j); z0 = q.x; z1 = q.y; } else { z0 = g.ns.arr[j]; z1 = 0.0; } }
-            else normal_pair(g.ns.key, g.ns.purpose, g.ns.call, 0, (uint32_t)(j >> 1), z0, z1);
-            x8[2 * i] = Model<MODEL>::transition(x8[2 * i], z0, g.par);
-            x8[2 * i + 1] = Model<MODEL>::transition(x8[2 * i + 1], z1, g.par);
+            x8[2 * i] = Model<MODEL>::transition(x8[2 * i], z8[2 * i], g.par);
+            x8[2 * i + 1] = Model<MODEL>::transition(x8[2 * i + 1], z8[2 * i + 1], g.par);
         }
         l8[2 * i] = (j < N) ? r_dnorm_log(g.y, x8[2 * i], g.par.sy, g.par.log_sy) : -INFINITY;
         l8[2 * i + 1] = (j + 1 < N) ? r_dnorm_log(g.y, x8[2 * i + 1], g.par.sy, g.par.log_sy) : -INFINITY;
@@ -458,7 +467,8 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
         __syncthreads();
         FZ_STAMP(3); FZ_GDONE(0);
         uint32_t status = 0;
-        double M = 0.0, S = 0.0, sq = 0.0;
+        double M = 0.0, S = 0.0, sq = 0.0, ess1 = 0.0;
+        bool book = false;
         double esv[2] = {0.0, 0.0}, pre = 0.0;
         if (!fs.bail) {
             double pmv[2], psv[2], pqv[2];
@@ -487,17 +497,9 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
                 for (int i = 0; i < wave; i++) pre += sm.sh4[i];
                 S = tree_sum<NWV>(sm.sh4);
                 sq = tree_sum<NWV>(sm.sh4 + 8);
-                const double ess = 1.0 / (sq / (S * S));                                          // :211
-                const int doit = (g.resample_algorithm == 0) ? 0 : (g.resample_algorithm == 1) ? 1 : (ess < g.threshold);   // :214-218
-                if (t == 0) {
-                    const double ll = st->loglike + (M + log(S) - log((double)N));                // :208
-                    st->loglike = ll; g.llh_out[g.obs_i - 1] = ll;                                // :209
-                    st->do_resample = doit;
-                    g.ess_out[g.obs_i] = doit ? (double)N : ess;                                  // :212,:223
-                    if (g.resampled_out) g.resampled_out[g.obs_i - 1] = doit;
-                    st->ess = ess; st->lse_max = M; st->lse_sum = S;
-                    if (doit) { st->cur_call = call; st->res_calls = call + 1; }
-                }
+                ess1 = 1.0 / (sq / (S * S));                                                      // :211
+                const int doit = (g.resample_algorithm == 0) ? 0 : (g.resample_algorithm == 1) ? 1 : (ess1 < g.threshold);   // :214-218
+                book = true;                   // (the run-state bookkeeping follows the answers: the workers are waiting for those)
                 status = doit ? FZ_ST_DOIT : 0u;
                 if (doit && (!(S > 0.0) || !isfinite(S) || !isfinite(M))) {                      // NaN/Inf log-weights: the scan stands down
                     if (t == 0) atomicOr(&st->flags, FLAG_NONFINITE);
@@ -520,6 +522,18 @@ __global__ __launch_bounds__(NT) void k_obs(FusedArgs g, DevState* st)
                 fz_u64* rep = &g.ws->c1[t][0];
                 fz_put64(rep + 0, g.tag, d2b(M)); fz_put64(rep + 2, g.tag, d2b(S)); fz_put64(rep + 4, g.tag, d2b(sq)); fz_put(rep + 6, g.tag, status);
             }
+        }
+        if (book && t == 0) {
+            // log-likelihood, ESS, decision into the run state (:208-223) -- behind the answers: st->loglike is a load from HBM
+            // and the two logs are ~100 instructions of one lane, neither of which the workers need
+            const int doit = (status & FZ_ST_DOIT) ? 1 : 0;
+            const double ll = st->loglike + (M + log(S) - log((double)N));                        // :208
+            st->loglike = ll; g.llh_out[g.obs_i - 1] = ll;                                        // :209
+            st->do_resample = doit;
+            g.ess_out[g.obs_i] = doit ? (double)N : ess1;                                         // :212,:223
+            if (g.resampled_out) g.resampled_out[g.obs_i - 1] = doit;
+            st->ess = ess1; st->lse_max = M; st->lse_sum = S;
+            if (doit) { st->cur_call = call; st->res_calls = call + 1; }
         }
     }
     if (resolver) FZ_STAMP(4);

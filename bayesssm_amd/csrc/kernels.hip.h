@@ -729,6 +729,10 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int j)
 // (Round 3 tried the opposite split: lane j's constants read into scalar registers one link ahead (13 v_readlane per link) and the link
 //  evaluated on the scalar unit.  The compiler does emit s_cselect / s_lshr_b64 / s_add for it, but the chain of 10 links took 3.9k cycles
 //  against 2.6k here: the readlanes cost more than the VALU -> SGPR round trip they remove.  profiles/r03_c_rejected_variants.txt)
+// (Round 3, third attempt at the ~260 cycles a link: the state kept in vector registers and handed from link to link by DPP row_newbcast:J
+//  -- 16 unrolled steps per row, no v_readlane, no SGPR, no data-dependent branch; accept bits broadcast the same way.  Bit-identical
+//  (225 GPU tests), but SLOWER: the fused launch 48.2 -> 48.8 us, k_local<P> 11.17 -> 11.45: ~30 vector instructions a link with the
+//  DPP wait states and three unrolled copies of 16 steps in the instruction stream cost more than three readlanes.  Removed.)
 __device__ __forceinline__ int walk_chain_regs(const WalkFn& w, int nent, uint64_t& s, uint64_t& my_s, uint64_t& my_out)
 {
     const int lane = threadIdx.x & 63;
@@ -765,7 +769,7 @@ struct SegSmem {
     Pure bnd_excl[MAXBND]; Rec bnd_rec[MAXBND]; int bnd_lane[MAXBND]; uint64_t bnd_ent[MAXBND];
     double bnd_terms[MAXBND][EL];    // the terms of every boundary lane (so a literal re-run never chases global memory)
     uint64_t seg_start[MAXBND + 1];
-    long long red_min[NWV][2], red_max[NWV][2];
+    int red_min[NWV][2], red_max[NWV][2];
     uint64_t segbase[MAXBND + 1];    // hypothesis base of every segment = that of its first lane (published by block_scan: no barrier round later)
     int wlastb[16];                  // per wave: its last lane is a boundary
     int smin[MAXBND + 1]; int smax[MAXBND + 1];
@@ -1109,17 +1113,25 @@ __device__ __forceinline__ int wave_max_i32(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 __device__ __forceinline__ int sat_i32(long long x) { return x > 0x7fffffffll ? 0x7fffffff : (x < -0x7fffffffll ? -0x7fffffff : (int)x); }
-__device__ __forceinline__ void block_minmax2(SegSmem& sm, long long mn[2], long long mx[2])
+// Window values travel as 32-bit integers saturated at +-WSAT = +-(2^30 + 2^24): every consumer clamps to +-2^30 in the end, and the margin
+// keeps  -lim - x + 4  and friends (lim < 2^23) inside int32 AND on the same side of +-2^30 as the exact 64-bit value, so the clamped
+// result is the 64-bit code's result for every input (round 3: the 64-bit form of this arithmetic was ~400 dependent instructions on the
+// four lanes that compose a crossing block's record, and every grid-level resolve waits for the last record).
+constexpr int WSAT = (1 << 30) + (1 << 24);
+__device__ __forceinline__ int sat_w(long long x) { return x > (long long)WSAT ? WSAT : (x < -(long long)WSAT ? -WSAT : (int)x); }
+__device__ __forceinline__ int clamp30i(int x) { return x < -(1 << 30) ? -(1 << 30) : (x > (1 << 30) ? (1 << 30) : x); }
+__device__ __forceinline__ void block_minmax2(SegSmem& sm, int mn[2], int mx[2])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int a0 = wave_min_i32(sat_i32(mn[0])), a1 = wave_min_i32(sat_i32(mn[1]));
-    const int b0 = wave_max_i32(sat_i32(mx[0])), b1 = wave_max_i32(sat_i32(mx[1]));
+    const int a0 = wave_min_i32(mn[0]), a1 = wave_min_i32(mn[1]);
+    const int b0 = wave_max_i32(mx[0]), b1 = wave_max_i32(mx[1]);
     if (lane == 0) { sm.red_min[wave][0] = a0; sm.red_min[wave][1] = a1; sm.red_max[wave][0] = b0; sm.red_max[wave][1] = b1; }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        long long a = sm.red_min[0][s], b = sm.red_max[0][s];
-        for (int wv = 1; wv < NWV; wv++) { a = sm.red_min[wv][s] < a ? sm.red_min[wv][s] : a; b = sm.red_max[wv][s] > b ? sm.red_max[wv][s] : b; }
+        int a = sm.red_min[0][s], b = sm.red_max[0][s];
+#pragma unroll
+        for (int wv = 1; wv < NWV; wv++) { a = min(a, sm.red_min[wv][s]); b = max(b, sm.red_max[wv][s]); }
         mn[s] = a; mx[s] = b;
     }
 }
@@ -1177,12 +1189,12 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
     int fb = NT;
     uint64_t seg1_base = 0;
     if (bs.nb > 0) { fb = sm.bnd_lane[0]; seg1_base = sm.segbase[1]; }       // (segbase[1]: only meaningful -- and only used -- when segment 1 has a lane)
-    long long mn[2] = {(1ll << 40), (1ll << 40)}, mx[2] = {-(1ll << 40), -(1ll << 40)};
+    int mn[2] = {WSAT, WSAT}, mx[2] = {-WSAT, -WSAT};          // (no lane in the segment: no constraint, as +-2^40 was in the 64-bit form)
     if (!bs.isb && bs.seg <= 1) {
         const uint64_t sb = (bs.seg == 0) ? hb0 : (seg1_base & ~3ull);
         const long long m0 = (long long)(sb + (uint64_t)bs.exc.d0 - bs.leaf.base);
         const long long m1 = (long long)(sb + 1 + (uint64_t)bs.exc.d1 - bs.leaf.base);
-        const long long lo_ = m0 < m1 ? m0 : m1, hi_ = m0 > m1 ? m0 : m1;
+        const int lo_ = sat_w(m0 < m1 ? m0 : m1), hi_ = sat_w(m0 > m1 ? m0 : m1);
         if (bs.seg == 0) { mn[0] = lo_; mx[0] = hi_; } else { mn[1] = lo_; mx[1] = hi_; }   // no runtime index: keeps mn/mx in registers
     }
     block_minmax2(sm, mn, mx);
@@ -1190,7 +1202,7 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
     // segment-0 prefix record: lanes [0, fb)
     if (bs.nb == 0) {
         if (t == NT - 1) {
-            BlockRec br; br.prefix = pure_to_rec(bs.last_seg, hb0, -(long long)lim - mn[0] + 4, (long long)lim - mx[0] - 4);
+            BlockRec br; br.prefix = pure_to_rec(bs.last_seg, hb0, (long long)clamp30i(-lim - mn[0] + 4), (long long)clamp30i(lim - mx[0] - 4));
             br.tail_from = NT; br.nside = 0; sink.rec(br);
         }
         return;
@@ -1202,48 +1214,54 @@ __device__ __forceinline__ void block_record_tail(SegSmem& sm, uint64_t* tin, co
     if (t < 4) {
         const Pure ex0 = sm.bnd_excl[0];                     // composite of segment 0 (the first boundary lane's exclusive scan)
         const Rec leaf = sm.bnd_rec[0];
-        const long long C30 = (1ll << 30);
-        auto clamp30 = [&](long long x) { return x < -C30 ? -C30 : (x > C30 ? C30 : x); };
+        const int C30 = 1 << 30;
         // (lanes 0..3 are one DPP quad: quad_perm [1,0,3,2] = 0xB1 and [2,3,0,1] = 0x4E exchange with lane ^ 1 and lane ^ 2)
-        auto min4 = [&](long long x) { long long y = dpp_i64<0xB1, 0xf>(x, x); x = y < x ? y : x; y = dpp_i64<0x4E, 0xf>(x, x); return y < x ? y : x; };
-        auto max4 = [&](long long x) { long long y = dpp_i64<0xB1, 0xf>(x, x); x = y > x ? y : x; y = dpp_i64<0x4E, 0xf>(x, x); return y > x ? y : x; };
+        auto min4 = [&](int x) { x = min(x, dpp_i32<0xB1, 0xf>(x, x)); return min(x, dpp_i32<0x4E, 0xf>(x, x)); };
+        auto max4 = [&](int x) { x = max(x, dpp_i32<0xB1, 0xf>(x, x)); return max(x, dpp_i32<0x4E, 0xf>(x, x)); };
         // pre = rec_identity(hb0) or pure_to_rec(ex0, hb0, ...): this lane's hypothesis
         const uint64_t pbase = hb0 & ~3ull;
-        const long long plo = (fb == 0) ? -C30 : clamp30(-(long long)lim - mn[0] + 4), phi = (fb == 0) ? C30 : clamp30((long long)lim - mx[0] - 4);
+        const int plo = (fb == 0) ? -C30 : clamp30i(-lim - mn[0] + 4), phi = (fb == 0) ? C30 : clamp30i(lim - mx[0] - 4);
         const uint64_t po = pbase + (uint64_t)t + ((fb == 0) ? 0ull : (uint64_t)((t & 1) ? ex0.d1 : ex0.d0));
         bool done1 = false;
-        uint64_t fo = 0; long long flo = 0, fhi = 0;
+        uint64_t fo = 0; int flo = 0, fhi = 0;
         BSSM_STAMP(st, dbg, 2, 5, stamper);
         if (bs.nb == 1 && leaf.kind == REC_X1) {
             // r = rec_compose(pre, leaf)
             bool ok = true;
             {
-                const long long m = (long long)(po - leaf.base);
-                long long lo = (long long)leaf.lo - min4(m) + 8, hi = (long long)leaf.hi - max4(m) - 8;
-                lo = lo < plo ? plo : lo; hi = hi > phi ? phi : hi;
-                ok = !(lo > 0 || hi < 3);
                 const int64_t diff = (int64_t)(po - leaf.base);
-                ok = ok && !(diff < (int64_t)leaf.lo || diff > (int64_t)leaf.hi);
+                const int m = sat_w(diff);
+                // (|leaf.lo|, |leaf.hi| <= 2^30 and mm within +-(2^30 - 16): the sums stay inside int32; a lane whose diff lies beyond that
+                //  fails the range test below, so the record is refused whatever lo / hi say -- as in the 64-bit form)
+                const int mm = m < -(C30 - 16) ? -(C30 - 16) : (m > C30 - 16 ? C30 - 16 : m);
+                int lo = leaf.lo - min4(mm) + 8, hi = leaf.hi - max4(mm) - 8;
+                lo = max(lo, plo); hi = min(hi, phi);
+                ok = !(lo > 0 || hi < 3);
+                ok = ok && !(m < leaf.lo || m > leaf.hi);
                 const int64_t sx = diff & 3, q4 = diff - sx;
                 const uint64_t os = (sx == 0) ? leaf.o[0] : (sx == 1) ? leaf.o[1] : (sx == 2) ? leaf.o[2] : leaf.o[3];
-                fo = os + (uint64_t)(q4 >> 1); flo = (long long)(int32_t)lo; fhi = (long long)(int32_t)hi;
+                fo = os + (uint64_t)(q4 >> 1); flo = lo; fhi = hi;
             }
             ok = __all(ok);                                       // (lanes 0..3 are the active ones here)
             BSSM_STAMP(st, dbg, 2, 6, stamper);
             if (ok && fb < NT - 1) {
                 // r = rec_compose(r, post),  post = pure_to_rec(last_seg, seg1_base, ...)
                 const uint64_t gbase = seg1_base & ~3ull;
-                const long long glo = clamp30(-(long long)lim - mn[1] + 4), ghi = clamp30((long long)lim - mx[1] - 4);
-                const long long m = (long long)(fo - gbase);
-                long long lo = (glo - min4(m) + 8) * 2, hi = (ghi - max4(m) - 8) * 2;
-                lo = lo < flo ? flo : lo; hi = hi > fhi ? fhi : hi;
-                bool ok2 = !(lo > 0 || hi < 3);
+                const int glo = clamp30i(-lim - mn[1] + 4), ghi = clamp30i(lim - mx[1] - 4);
                 const int64_t diff = (int64_t)(fo - gbase);
-                ok2 = ok2 && !(diff < (int64_t)glo || diff > (int64_t)ghi);
+                const int m = sat_w(diff);
+                // (the factor 2: a crossing halves the distance.  Clamped to +-(2^30 - 1) before doubling: beyond that the exact double is
+                //  below every flo / above every fhi, or makes the record invalid -- the same outcome)
+                auto dbl = [&](int x) { const int c = x < -(C30 - 1) ? -(C30 - 1) : (x > C30 - 1 ? C30 - 1 : x); return 2 * c; };
+                const int mm = m < -(C30 - 16) ? -(C30 - 16) : (m > C30 - 16 ? C30 - 16 : m);
+                int lo = dbl(glo - min4(mm) + 8), hi = dbl(ghi - max4(mm) - 8);
+                lo = max(lo, flo); hi = min(hi, fhi);
+                bool ok2 = !(lo > 0 || hi < 3);
+                ok2 = ok2 && !(m < glo || m > ghi);
                 const int64_t sx = diff & 3, q4 = diff - sx;
                 // post.o[sx] = gbase + sx + (sx odd ? d1 : d0)
                 fo = gbase + (uint64_t)sx + (uint64_t)((sx & 1) ? bs.last_seg.d1 : bs.last_seg.d0) + (uint64_t)q4;
-                flo = (long long)(int32_t)lo; fhi = (long long)(int32_t)hi;
+                flo = lo; fhi = hi;
                 ok = __all(ok2);
             }
             done1 = ok;
