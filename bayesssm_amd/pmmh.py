@@ -526,9 +526,19 @@ def _pmmh_closures(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, 
             param_transform = dict(param_transform, **{k: "identity" for k in bad})
     transform = [param_transform[k] for k in prior_names]
     priors = [log_priors[k] for k in prior_names]
+    r_stream = bool(kwargs.pop("r_stream", False))
     if seed is None:
+        if r_stream:
+            raise ValueError("r_stream needs a seed (the argument of set.seed)")
         seed = int(np.random.default_rng().integers(1, 2 ** 31 - 1))
-    seeds = np.random.default_rng(seed).integers(1, 2 ** 31 - 1, size=num_chains)            # R/pmmh.R:511
+    if r_stream:
+        # the call as R executes it: chain seeds by sample.int from set.seed(seed); per chain set.seed(seeds[c]) (below) seeds THE generator
+        # (resampling._rng) that the resampling draws, the MH draws and -- if the user's closures draw from it too -- the model draws
+        # consume in R's order; MASS::mvrnorm on LAPACK's eigenvectors
+        from .rrng import RRandom, sample_int_large
+        seeds = np.array(sample_int_large(RRandom(int(seed)), 2147483647, num_chains))       # R/pmmh.R:255-256,511
+    else:
+        seeds = np.random.default_rng(seed).integers(1, 2 ** 31 - 1, size=num_chains)        # R/pmmh.R:511
     print_result = bool(kwargs.pop("print_result", True))
     ctx = kwargs.pop("ctx", None)
     dist = None
@@ -560,6 +570,9 @@ def _pmmh_closures(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, 
         set_seed(int(seeds[c]))                                       # set.seed(seed) (:346): the resampling stream of this chain
         calls["seed"], calls["n"] = int(seeds[c]), 0
         rng = np.random.default_rng([int(seeds[c]), 77])
+        if r_stream:
+            from . import resampling as _rs
+            rng = _RStreamRng(_rs._rng)
         if verbose:
             print("Running chain %d..." % (c + 1)); print("Running pilot chain for tuning...")
         pilot = run_pilot_chain(
@@ -571,7 +584,7 @@ def _pmmh_closures(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, 
         if verbose:
             print("Running Particle MCMC chain with tuned settings...")
         out = run_chain_host(lambda th: run_pf(th, pilot["target_n"]), m, pilot["pilot_theta_mean"], pilot["pilot_theta_cov"],
-                             transform, priors, rng, return_latent_state_est)
+                             transform, priors, rng, return_latent_state_est, mvrnorm=(_mvrnorm_lapack if r_stream else None))
         out["pilot"] = pilot
         local[c], extras_out[c] = out["theta_chain"], out
     n_params = len(prior_names)

@@ -101,3 +101,88 @@ def test_reference_seeded_filter_test_in_r_stream(B):
     assert len(res["state_est"]) == len(xs)
     rmse = float(np.sqrt(np.mean((np.asarray(res["state_est"]) - xs) ** 2)))
     assert rmse < 0.5, rmse
+
+
+def _drift_setup(B, sigma):
+    """The data block shared by tests/testthat/test-auxiliary_filter.R:2-16 and test-resample_move_filter.R:2-16, drawn from R's stream
+    after set.seed(1405), and the tests' closures drawing from the SAME generator (closure mode: the host evaluates the closures, the
+    device does everything the core does with their log-weights, the resampling uniforms come from the same R stream)."""
+    from bayesssm_amd import resampling as rs
+    from bayesssm_amd.rrng import rnorm_vec
+    B.set_seed(1405)
+    g = rs._rng
+    T, mu = 50, 1.0
+    x, y = np.zeros(T + 1), np.zeros(T)
+    x[0] = 0.0 + 1.0 * g.norm_rand()
+    for t in range(T):
+        x[t + 1] = x[t] + (mu + 1.0 * g.norm_rand())
+        y[t] = x[t + 1] + sigma * g.norm_rand()
+
+    def dnorm_log(yv, mean, sd):
+        z = np.abs((yv - mean) / sd)
+        return -(0.918938533204672741780329736406 + 0.5 * z * z + np.log(sd))
+
+    fns = dict(
+        init_fn=lambda num_particles: 0.0 + 1.0 * rnorm_vec(g, num_particles),
+        transition_fn=lambda particles, mu: particles + (mu + 1.0 * rnorm_vec(g, len(particles))),
+        log_likelihood_fn=lambda y, particles, sigma: dnorm_log(y, particles, sigma),
+        aux_log_likelihood_fn=lambda y, particles, mu, sigma: dnorm_log(y, particles + mu, sigma))
+
+    def move_fn(particle, y, sigma):
+        proposal = particle + (0.0 + 0.1 * g.norm_rand())
+        lc, lp = dnorm_log(y, particle, sigma), dnorm_log(y, proposal, sigma)
+        return proposal if np.log(g.unif_rand()) < (lp - lc) else particle
+    return x, y, mu, fns, move_fn
+
+
+def test_reference_seeded_apf_test_in_r_stream(B):
+    """tests/testthat/test-auxiliary_filter.R:1-54 as R runs it (one stream: data, bootstrap filter, auxiliary filter; N = 20, wrapper
+    defaults): the reference asserts mse(apf) < mse(bpf)."""
+    sigma = 0.1
+    x, y, mu, f, _ = _drift_setup(B, sigma)
+    bpf = B.bootstrap_filter(y, 20, f["init_fn"], f["transition_fn"], f["log_likelihood_fn"], mu=mu, sigma=sigma)
+    apf = B.auxiliary_filter(y, 20, f["init_fn"], f["transition_fn"], f["log_likelihood_fn"], f["aux_log_likelihood_fn"], mu=mu, sigma=sigma)
+    mse_bpf = float(np.mean((np.asarray(bpf["state_est"]).reshape(-1) - x) ** 2))
+    mse_apf = float(np.mean((np.asarray(apf["state_est"]).reshape(-1) - x) ** 2))
+    assert mse_apf < mse_bpf, (mse_apf, mse_bpf)
+
+
+def test_reference_seeded_rmpf_test_in_r_stream(B):
+    """tests/testthat/test-resample_move_filter.R:1-66 as R runs it (sigma = 0.05: strong degeneracy): mse(rmpf) < mse(bpf)."""
+    sigma = 0.05
+    x, y, mu, f, move_fn = _drift_setup(B, sigma)
+    bpf = B.bootstrap_filter(y, 20, f["init_fn"], f["transition_fn"], f["log_likelihood_fn"], mu=mu, sigma=sigma)
+    rmpf = B.resample_move_filter(y, 20, f["init_fn"], f["transition_fn"], f["log_likelihood_fn"], move_fn, mu=mu, sigma=sigma)
+    mse_bpf = float(np.mean((np.asarray(bpf["state_est"]).reshape(-1) - x) ** 2))
+    mse_rmpf = float(np.mean((np.asarray(rmpf["state_est"]).reshape(-1) - x) ** 2))
+    assert mse_rmpf < mse_bpf, (mse_rmpf, mse_bpf)
+
+
+def test_reference_seeded_multi_dim_pmmh_test_in_r_stream(B, capsys):
+    """tests/testthat/test-pmmh.R:618-668 as R runs it: a 2-dimensional random walk with drift phi, constant likelihood, phi ~ N(0, 1), default
+    tuning (pilot_m = 2000, pilot_n = 100, pilot_reps = 100), m = 500, two chains, seed = 1405; the reference asserts
+    expect_equal(mean(phi), 0, tolerance = 0.1) -- under ITS seeded stream.  Here: closure mode (the closures draw from the call's R
+    stream; ~5 200 filter runs whose only effect is to advance the stream by exactly 2 N (T + 1) normals each), MH draws from the same
+    stream: the chain is R's chain if every draw count along the way is right."""
+    from bayesssm_amd import resampling as rs
+    from bayesssm_amd.rrng import rnorm_vec
+
+    def init_fn(num_particles):                                   # matrix(rnorm(num_particles * 2), ncol = 2): column-major fill
+        return rnorm_vec(rs._rng, 2 * num_particles).reshape(2, num_particles).T.copy()
+
+    def transition_fn(particles, phi):                            # particles + rnorm(nrow(particles) * 2, mean = phi): recycled column-major
+        n = particles.shape[0]
+        return particles + (phi + 1.0 * rnorm_vec(rs._rng, 2 * n)).reshape(2, n).T
+
+    def log_likelihood_fn(y, particles):
+        return np.ones(particles.shape[0])
+
+    out = B.pmmh(B.bootstrap_filter, np.zeros(20), 500, init_fn, transition_fn, log_likelihood_fn, {"phi": B.prior_normal(0.0, 1.0)},
+                 [{"phi": 0.8}, {"phi": 0.5}], 100, num_chains=2, param_transform={"phi": "identity"}, seed=1405, r_stream=True,
+                 print_result=False)
+    printed = capsys.readouterr().out
+    assert printed.count("Using 50 particles for PMMH:") == 2      # var(loglik) = 0 -> max(ceiling(0), 50)
+    phi = np.asarray(out["theta_chain"]["phi"])
+    assert phi.shape == (800,)
+    assert list(out["_extras"]["seeds"]) == [461152368, 599335816]
+    assert abs(phi.mean()) < 0.1, phi.mean()                       # the reference's own assertion
