@@ -277,7 +277,10 @@ __device__ __forceinline__ uint64_t fz_resolve_duty(SegSmem& sm, ResolveSmem& rs
     const fz_u64* planes = (MODE == MODE_W) ? &g.ws->e2[0][0] : &g.ws->e3[0][0];
     const fz_u64* sides = (MODE == MODE_W) ? &g.ws->side_w[0][0][0] : &g.ws->side_p[0][0][0];
     const int CB = (B + NT - 1) / NT;
-    const int c0 = t * CB, c1 = (c0 + CB < B) ? c0 + CB : B;
+    // (cumsum pass: nobody needs the state BEHIND the last block, so its record -- the one that nearly always carries a side entry, published
+    //  ~0.5 us after the record itself and fetched with a round trip of its own -- is not waited for at all)
+    const int Bneed = (MODE == MODE_P) ? B - 1 : B;
+    const int c0 = t * CB, c1 = (c0 + CB < Bneed) ? c0 + CB : Bneed;
     uint32_t w0[FZ_KREC], w1[FZ_KREC];
     bool ok = fz_gather<FZ_KREC>(planes, c0, c1, g.tag, clk, &fs.bail, w0, w1);
     bool unsup = false;
