@@ -269,6 +269,32 @@ __device__ __forceinline__ bool fz_fetch_sides(const fz_u64* side_base, SideList
     return true;
 }
 
+// The last block's single side entry, fetched from the wire by the resolver's wave 0 at the moment the chain walk needs it (lane q polls
+// granule q; one round trip, usually none: the entry arrived while the scan ran) into the walk's LDS slot.
+struct FzLateSide {
+    static constexpr bool active = true;
+    const fz_u64* src; uint32_t tag; FzClock clk;
+    __device__ __forceinline__ bool operator()(SideEntry* dst) const
+    {
+        const int lane = threadIdx.x & 63;
+        static_assert(FZ_KSIDE <= 64, "one granule per lane");
+        for (unsigned spins = 0;; spins++) {
+            bool ok = true;
+            uint32_t v = 0;
+            if (lane < FZ_KSIDE) { const fz_u64 x = fz_get(src + lane); ok = (uint32_t)(x >> 32) == tag; v = (uint32_t)x; }
+            if (__all(ok)) {
+                if (lane < FZ_KSIDE) reinterpret_cast<uint32_t*>(dst)[lane] = v;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                return true;
+            }
+            if ((spins & 15u) == 15u && clk.expired()) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+};
+
 template <int MODE, bool EMIT>
 __device__ __forceinline__ uint64_t fz_resolve_duty(SegSmem& sm, ResolveSmem& rs, FusedSmem& fs, const FusedArgs& g, DevState* st, const FzClock& clk,
                                                     uint64_t* cin_lds /* [FZ_MAXB], EMIT */, bool& bail)
@@ -288,13 +314,24 @@ __device__ __forceinline__ uint64_t fz_resolve_duty(SegSmem& sm, ResolveSmem& rs
     q0.prefix = rec_identity(0); q0.tail_from = NT; q0.nside = 0; q1 = q0;
     if (ok) {
         // (the records stay in registers; only side entries -- the last block's, rarely another -- go through the private list)
+        // (the LAST block's single side entry is not waited for here: the walk fetches it when it gets there -- FzLateSide)
         if (c0 < c1) {
             bool u; q0 = fz_decode(w0, u); unsup = unsup || u;
-            if (!u && q0.nside > 0) ok = ok && fz_fetch_sides(sides, g.ws->side_priv[MODE], c0, q0.nside, g.tag, clk);
+            if (!u && q0.nside > 0 && !(c0 == B - 1 && q0.nside == 1 && q0.tail_from >= NT)) {
+#ifdef BSSM_DEV_STAMPS
+                g.ws->pubt[3][20 + MODE] = c0; atomicAdd((unsigned long long*)&g.ws->pubt[3][22 + MODE], 1ull);
+#endif
+                ok = ok && fz_fetch_sides(sides, g.ws->side_priv[MODE], c0, q0.nside, g.tag, clk);
+            }
         }
         if (c0 + 1 < c1) {
             bool u; q1 = fz_decode(w1, u); unsup = unsup || u;
-            if (!u && q1.nside > 0) ok = ok && fz_fetch_sides(sides, g.ws->side_priv[MODE], c0 + 1, q1.nside, g.tag, clk);
+            if (!u && q1.nside > 0 && !(c0 + 1 == B - 1 && q1.nside == 1 && q1.tail_from >= NT)) {
+#ifdef BSSM_DEV_STAMPS
+                g.ws->pubt[3][20 + MODE] = c0 + 1; atomicAdd((unsigned long long*)&g.ws->pubt[3][22 + MODE], 1ull);
+#endif
+                ok = ok && fz_fetch_sides(sides, g.ws->side_priv[MODE], c0 + 1, q1.nside, g.tag, clk);
+            }
         }
     }
     // (a wave that saw an unsupported record may have made the other waves leave their gather early: the larger code wins)
@@ -310,7 +347,8 @@ __device__ __forceinline__ uint64_t fz_resolve_duty(SegSmem& sm, ResolveSmem& rs
     // (cumsum pass: nobody needs the state BEHIND the last block -- its record, the one with the lanes next to cum == 1, stays out of the
     //  walk; the state in front of it is the walk's result)
     const int upto = (MODE == MODE_P) ? B - 1 : B;
-    const uint64_t fin = resolve_in_block<MODE, NT, EMIT>(sm, rs, g.ws->brec_priv[MODE], g.ws->side_priv[MODE], B, upto, g.xin, g.N, 1.0, st, true, cin_lds, &lit, &q0, &q1);
+    FzLateSide late; late.src = sides + ((size_t)(B - 1) * FZ_MAXSIDE + 0) * FZ_KSIDE; late.tag = g.tag; late.clk = clk;
+    const uint64_t fin = resolve_in_block<MODE, NT, EMIT, FzLateSide>(sm, rs, g.ws->brec_priv[MODE], g.ws->side_priv[MODE], B, upto, g.xin, g.N, 1.0, st, true, cin_lds, &lit, &q0, &q1, late);
     if (EMIT && t == 0) cin_lds[B - 1] = fin;
     if (lit >= LIT_FROM_W) fs.bail = 2;
     __syncthreads();

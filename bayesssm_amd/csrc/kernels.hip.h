@@ -1671,13 +1671,18 @@ __device__ __forceinline__ bool run_ok(const LaneRun& r, uint64_t ent)
 
 // NTX: threads of the calling workgroup (NT inside the scan kernels; NTR in k_resolve_all, which also EMITs every block's
 // exact incoming state to cin_out).
-template <int MODE, int NTX = NT, bool EMIT = false>
+// LateSide: where the LAST block's side entry comes from when it is not in `side` yet.  The multi-launch kernels read it from HBM at the
+// start (NoLateSide); the fused launch's resolver fetches it from the wire only when the walk reaches it -- that entry is published ~0.5 us
+// after its block's record, and waiting for it in front of the scan put it on every workgroup's critical path.
+struct NoLateSide { static constexpr bool active = false; __device__ __forceinline__ bool operator()(SideEntry*) const { return true; } };
+template <int MODE, int NTX = NT, bool EMIT = false, class LateSide = NoLateSide>
 __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& rs, const BlockRec* __restrict__ brec,
                                                      const SideList* __restrict__ side, const int B, const int upto,
                                                      const double* __restrict__ w, long long nw, double total, DevState* st,
                                                      const bool count_stats, uint64_t* __restrict__ cin_out = nullptr,
                                                      long long* lit_out = nullptr /* this thread's count of literally re-run terms */,
-                                                     const BlockRec* pre0 = nullptr, const BlockRec* pre1 = nullptr /* the thread's records, already in registers */)
+                                                     const BlockRec* pre0 = nullptr, const BlockRec* pre1 = nullptr /* the thread's records, already in registers */,
+                                                     const LateSide late = LateSide())
 {
     const int t = threadIdx.x;
     if (upto <= 0) return 0ull;                        // (block-uniform)
@@ -1694,7 +1699,7 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
     if (t == 0) { rs.sout[0] = 0; rs.fail = 0; }
     // the last block of a full pass nearly always carries one side entry (the lanes next to cum == 1.0 are never PURE):
     // fetch it now, with the records, so that the walk does not wait for a dependent global load later
-    if (upto == B && t >= NTX - (int)(sizeof(SideEntry) / 16)) {
+    if (!LateSide::active && upto == B && t >= NTX - (int)(sizeof(SideEntry) / 16)) {
         const int q = t - (NTX - (int)(sizeof(SideEntry) / 16));
         reinterpret_cast<uint4*>(&rs.sideC[63])[q] = reinterpret_cast<const uint4*>(&side[upto - 1].e[0])[q];
     }
@@ -1747,6 +1752,13 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
         BSSM_STAMP(st, dbg, MODE, 3, stamper && wfn.sh >= 0);
         const int j0 = walk_chain_regs(wfn, E, sw, my_s0, my_out);
         BSSM_STAMP(st, dbg, MODE, 4, stamper && sw != 1);
+        if constexpr (LateSide::active) {
+            // the last block's side entry (slot 63), if the walk is about to need it: the last link is block B - 1 with exactly one entry
+            if (upto == B && E > 0 && E <= 64) {
+                const int lb = __builtin_amdgcn_readlane(bidx, E - 1), ln = __builtin_amdgcn_readlane(nside, E - 1), ls = __builtin_amdgcn_readlane((int)slow, E - 1);
+                if (lb == B - 1 && ln == 1 && !ls) { if (!late(&rs.sideC[63])) lit += LIT_FROM_W; }      // (a time-out voids the fused result)
+            }
+        }
         for (int j = j0; j < E; j++) {
             bool ok;
             uint64_t o = stepfn_apply(fn, sw, ok);

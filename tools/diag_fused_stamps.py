@@ -101,3 +101,4 @@ for nm, a, b in (("phase A + partials (start -> publish)", st0, p[0][:Bn]), ("we
                  ("P scan (total -> publish)", wk[1], p[2][:Bn]), ("expansion (state -> end)", wk[2], e)):
     d = b - a
     print("   %-40s median %4d  p90 %4d  max %4d (block %d)" % (nm, np.median(d), np.percentile(d, 90), d.max(), int(d.argmax())))
+print("side-entry fetches in front of the scan, all launches of the run: W duty %d (last block fetched: %d), P duty %d (last: %d)" % (p[3][22], p[3][20], p[3][23], p[3][21]))
