@@ -224,24 +224,33 @@ __device__ __forceinline__ bool fz_gather(const fz_u64* planes, int c0, int c1, 
 {
     // two blocks per thread (c0 even): ONE 16-byte sc1 load per plane fetches both granules; each 8-byte half is one store of its
     // producer, checked by its own tag
-    const bool pair = ((c0 & 1) == 0) && (c0 + 1 < c1);
+    // (c0 even and c0 < c1: the 16-byte form always -- also when only the first of the two is wanted (the cumsum duty's last thread), so that
+    //  no wave runs both forms one after the other; FZ_MAXB is even, the second granule exists)
+    const bool pair = ((c0 & 1) == 0) && (c0 < c1);
+    const bool want1 = (c0 + 1 < c1);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<fz_u64*>(planes), 0, NG * FZ_MAXB * 8, 0x00020000);
+    // a lane whose records have arrived stops polling: the passes that wait for the last few records (the head block, the crossing blocks) then
+    // carry a handful of loads instead of 8 x 64 per wave and come back sooner
+    bool have = false;
     for (unsigned spins = 0;; spins++) {
-        bool ok = true;
-        if (pair) {
+        if (!have) {
+            bool ok = true;
+            if (pair) {
 #pragma unroll
-            for (int k = 0; k < NG; k++) {
-                const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(rs, (k * FZ_MAXB + c0) * 8, 0, 16);        // aux 16 = sc1
-                ok = ok && x.y == tag && x.w == tag; w0[k] = x.x; w1[k] = x.z;
-            }
-        } else {
+                for (int k = 0; k < NG; k++) {
+                    const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(rs, (k * FZ_MAXB + c0) * 8, 0, 16);        // aux 16 = sc1
+                    ok = ok && x.y == tag && (!want1 || x.w == tag); w0[k] = x.x; w1[k] = x.z;
+                }
+            } else {
 #pragma unroll
-            for (int k = 0; k < NG; k++) {
-                if (c0 < c1) { const fz_u64 x = fz_get(planes + (size_t)k * FZ_MAXB + c0); ok = ok && (uint32_t)(x >> 32) == tag; w0[k] = (uint32_t)x; }
-                if (c0 + 1 < c1) { const fz_u64 x = fz_get(planes + (size_t)k * FZ_MAXB + c0 + 1); ok = ok && (uint32_t)(x >> 32) == tag; w1[k] = (uint32_t)x; }
+                for (int k = 0; k < NG; k++) {
+                    if (c0 < c1) { const fz_u64 x = fz_get(planes + (size_t)k * FZ_MAXB + c0); ok = ok && (uint32_t)(x >> 32) == tag; w0[k] = (uint32_t)x; }
+                    if (c0 + 1 < c1) { const fz_u64 x = fz_get(planes + (size_t)k * FZ_MAXB + c0 + 1); ok = ok && (uint32_t)(x >> 32) == tag; w1[k] = (uint32_t)x; }
+                }
             }
+            have = ok;
         }
-        if (__all(ok)) return true;
+        if (__all(have)) return true;
         if ((spins & 15u) == 15u && clk.expired()) { *bail = 1; return false; }
         if (*(volatile int*)bail) return false;
         __builtin_amdgcn_s_sleep(1);
