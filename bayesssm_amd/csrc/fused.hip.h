@@ -283,16 +283,19 @@ __device__ __forceinline__ bool fz_fetch_sides(const fz_u64* side_base, SideList
 struct FzLateSide {
     static constexpr bool active = true;
     const fz_u64* src; uint32_t tag; FzClock clk;
-    __device__ __forceinline__ bool operator()(SideEntry* dst) const
+    __device__ __forceinline__ unsigned long long issue() const
     {
         const int lane = threadIdx.x & 63;
         static_assert(FZ_KSIDE <= 64, "one granule per lane");
+        return (lane < FZ_KSIDE) ? fz_get(src + lane) : 0ull;
+    }
+    __device__ __forceinline__ bool finish(SideEntry* dst, unsigned long long x) const
+    {
+        const int lane = threadIdx.x & 63;
         for (unsigned spins = 0;; spins++) {
-            bool ok = true;
-            uint32_t v = 0;
-            if (lane < FZ_KSIDE) { const fz_u64 x = fz_get(src + lane); ok = (uint32_t)(x >> 32) == tag; v = (uint32_t)x; }
+            const bool ok = (lane >= FZ_KSIDE) || ((uint32_t)(x >> 32) == tag);
             if (__all(ok)) {
-                if (lane < FZ_KSIDE) reinterpret_cast<uint32_t*>(dst)[lane] = v;
+                if (lane < FZ_KSIDE) reinterpret_cast<uint32_t*>(dst)[lane] = (uint32_t)x;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -300,6 +303,7 @@ struct FzLateSide {
             }
             if ((spins & 15u) == 15u && clk.expired()) return false;
             __builtin_amdgcn_s_sleep(1);
+            if (lane < FZ_KSIDE) x = fz_get(src + lane);
         }
     }
 };

@@ -1674,7 +1674,11 @@ __device__ __forceinline__ bool run_ok(const LaneRun& r, uint64_t ent)
 // LateSide: where the LAST block's side entry comes from when it is not in `side` yet.  The multi-launch kernels read it from HBM at the
 // start (NoLateSide); the fused launch's resolver fetches it from the wire only when the walk reaches it -- that entry is published ~0.5 us
 // after its block's record, and waiting for it in front of the scan put it on every workgroup's critical path.
-struct NoLateSide { static constexpr bool active = false; __device__ __forceinline__ bool operator()(SideEntry*) const { return true; } };
+struct NoLateSide {
+    static constexpr bool active = false;
+    __device__ __forceinline__ unsigned long long issue() const { return 0ull; }
+    __device__ __forceinline__ bool finish(SideEntry*, unsigned long long) const { return true; }
+};
 template <int MODE, int NTX = NT, bool EMIT = false, class LateSide = NoLateSide>
 __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& rs, const BlockRec* __restrict__ brec,
                                                      const SideList* __restrict__ side, const int B, const int upto,
@@ -1728,6 +1732,9 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
         // ---- boundary walk, one wave: lane j owns link j ----
         const int lane = t;
         const bool have = lane < E;
+        // (the last block's side entry: the loads go out now, ~4k cycles of link set-up and chain walk before the value is looked at)
+        unsigned long long late_v = 0ull;
+        if constexpr (LateSide::active) { if (upto == B) late_v = late.issue(); }
         int bidx = -1;
         Pure ex; ex.d0 = 0; ex.d1 = 0;
         Rec pr = rec_identity(0);
@@ -1756,7 +1763,7 @@ __device__ __forceinline__ uint64_t resolve_in_block(SegSmem& sm, ResolveSmem& r
             // the last block's side entry (slot 63), if the walk is about to need it: the last link is block B - 1 with exactly one entry
             if (upto == B && E > 0 && E <= 64) {
                 const int lb = __builtin_amdgcn_readlane(bidx, E - 1), ln = __builtin_amdgcn_readlane(nside, E - 1), ls = __builtin_amdgcn_readlane((int)slow, E - 1);
-                if (lb == B - 1 && ln == 1 && !ls) { if (!late(&rs.sideC[63])) lit += LIT_FROM_W; }      // (a time-out voids the fused result)
+                if (lb == B - 1 && ln == 1 && !ls) { if (!late.finish(&rs.sideC[63], late_v)) lit += LIT_FROM_W; }      // (a time-out voids the fused result)
             }
         }
         for (int j = j0; j < E; j++) {
