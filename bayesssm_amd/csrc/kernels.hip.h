@@ -995,7 +995,11 @@ __device__ __forceinline__ bool block_resolve(SegSmem& sm, const BlockScan& bs, 
     __syncthreads();
     // Boundary walk by wave 0: lane k holds boundary k's record in registers; the exact state is handed from lane
     // to lane with v_readlane, so a step costs one record evaluation and no memory round trip.
-    if (t < 64 && bs.nb <= MAXBND) {
+    if (t < 64 && bs.nb == 0) {
+        // no boundary in this block (nearly every block): nothing to walk -- and no step functions to build for an empty chain (~100
+        // 64-bit operations that every workgroup used to spend here, between the arrival of its exact state and its expansion)
+        if (t == 0) sm.seg_start[0] = cin;
+    } else if (t < 64 && bs.nb <= MAXBND) {
         const int lane = t, nb = bs.nb;
         Rec rec = rec_identity(0);
         Pure ex; ex.d0 = 0; ex.d1 = 0;
