@@ -332,6 +332,15 @@ typedef struct {
     double move_sd;
     const double *z_move;   /* [T][N]: the rnorm(1, 0, sd) draw of each particle's move */
     const double *u_move;   /* [T][N]: its runif(1) draw */
+    /* A long run in slices (test infrastructure: T x N draws of BASELINE's largest configuration do not fit in memory at once).  The core
+     * carries NOTHING from one observation to the next but the particles (the weights are rebuilt from the new log-weights alone,
+     * R/particle_filter_core.R:204-207) and the running log-likelihood, which the caller adds up: a slice started from the particles the
+     * previous slice ended with continues the run exactly.  x_start != NULL: the particles [d][N] to start from (z_init is not read, the
+     * t = 0 outputs describe x_start under uniform weights); x_end: the particles after the last observation (optional); loglike_start:
+     * the running sum so far, so that the slice's additions are the whole run's additions bit for bit. */
+    const double *x_start;
+    double *x_end;
+    double loglike_start;   /* the running log-likelihood the slice continues from (0 for a whole run) */
 } orc_pf_args;
 
 /* R sum(): long double accumulator (R summary.c rsum), rounded once. */
@@ -378,7 +387,8 @@ int orc_pf_run(orc_pf_args *a)
     *a->early_return_step = 0;
 
     /* init_fn: rnorm(N, 0, 1) :76   (SIR: every particle at (s0, i0), stochastic-sir-model.Rmd:286-293) */
-    if (sir) { for (int i = 0; i < N; i++) { x[i] = a->theta[3]; x[N + i] = a->theta[4]; } }
+    if (a->x_start) memcpy(x, a->x_start, sizeof(double) * N * D);
+    else if (sir) { for (int i = 0; i < N; i++) { x[i] = a->theta[3]; x[N + i] = a->theta[4]; } }
     else for (int i = 0; i < N; i++) x[i] = orc_rnorm(0.0, 1.0, a->z_init[i]);
 
     /* t = 0 :106-116.  weights = rep(1/N, N); ess[1] = 1/sum(w^2); state_est[1] = sum(x*w) */
@@ -392,7 +402,7 @@ int orc_pf_run(orc_pf_args *a)
     if (a->weights_hist) memcpy(a->weights_hist, w, sizeof(double) * N);
     if (a->particles_hist) memcpy(a->particles_hist, x, sizeof(double) * N * D);
 
-    double loglike = 0.0;
+    double loglike = a->x_start ? a->loglike_start : 0.0;
     int prev_t = 0;
     for (int i = 1; i <= T; i++) {                            /* :123 */
         const int ot = a->obs_times ? a->obs_times[i - 1] : i;
@@ -491,6 +501,7 @@ done:
     *a->loglike = loglike;
     *a->n_trans_calls = ktrans;
     *a->n_res_calls = kres;
+    if (a->x_end) memcpy(a->x_end, x, sizeof(double) * N * D);
     free(x); free(xold); free(lw); free(auxlw); free(w); free(tmp); free(idx);
     return rc;
 }

@@ -53,6 +53,7 @@ class _PfArgs(C.Structure):
         ("n_trans_calls", C.c_void_p), ("n_res_calls", C.c_void_p),
         ("early_return_step", C.c_void_p), ("resampled", C.c_void_p),
         ("move_sd", C.c_double), ("z_move", C.c_void_p), ("u_move", C.c_void_p),
+        ("x_start", C.c_void_p), ("x_end", C.c_void_p), ("loglike_start", C.c_double),
     ]
 
 
@@ -134,7 +135,7 @@ def noise_shape(algorithm, T, obs_times=None):
 def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
            resample_algorithm="SISAR", resample_fn="stratified", threshold=None,
            obs_times=None, return_ancestors=False, return_particles=False, seed=0, stream=0,
-           move_sd=0.0, z_move=None, u_move=None):
+           move_sd=0.0, z_move=None, u_move=None, x_start=None, loglike_start=0.0, return_x_end=False):
     """Restatement of .particle_filter_core (R/particle_filter_core.R:19-267)
     with injected random draws.  Returns a dict shaped like the reference's
     result list (state_est, ess, loglike, loglike_history, algorithm[,
@@ -164,13 +165,17 @@ def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
     ph = np.full((T + 1, N * D), np.nan) if return_particles else None
     nt, nr, ers = (np.zeros(1, dtype=np.int32) for _ in range(3))
     resampled = np.zeros(max(T, 1), dtype=np.int32)
+    # a long run in slices: start from the previous slice's particles / running log-likelihood, hand this slice's back (orc_pf_args)
+    xs = _d(x_start) if x_start is not None else None
+    xe = np.zeros(N * D) if return_x_end else None
     a = _PfArgs(MODEL[model], ALGORITHM[algorithm], RESAMPLE_ALGORITHM[resample_algorithm],
                 RESAMPLE_FN[resample_fn], N, T,
                 float("nan") if threshold is None else float(threshold),
                 _p(theta), _p(y), _p(ot), _p(z_init), _p(z_trans), _p(u_res), int(seed), int(stream),
                 _p(state_est), _p(ess), _p(llh), _p(ll), _p(anc), _p(wh), _p(ph),
                 _p(nt), _p(nr), _p(ers), _p(resampled), float(move_sd),
-                _p(_d(z_move)) if z_move is not None else None, _p(_d(u_move)) if u_move is not None else None)
+                _p(_d(z_move)) if z_move is not None else None, _p(_d(u_move)) if u_move is not None else None,
+                _p(xs), _p(xe), float(loglike_start))
     st = lib().orc_pf_run(C.byref(a))
     if st:
         raise ResampleError(st)
@@ -185,6 +190,8 @@ def pf_run(model, theta, y, N, z_init, z_trans, u_res, algorithm="BPF",
     if return_particles:
         res["particles_history"] = ph
         res["weights_history"] = wh
+    if return_x_end:
+        res["x_end"] = xe
     return res
 
 
