@@ -90,6 +90,7 @@ static std::atomic<int> g_fused_busy[64];
 // multi-launch).  So: runs in flight per device are counted, and after any overlap the next FZ_QUIET runs of the device stay multi-launch.
 static std::atomic<int> g_runs_active[64];
 static std::atomic<long long> g_run_serial[64], g_last_overlap[64];
+static std::atomic<long long> g_fused_hold[64], g_fused_span[64];       // back-off after a time-out: no fused run before serial `hold`; `span` doubles while they keep coming
 constexpr long long FZ_QUIET = 16;
 
 static int pool_get(bssm_ctx* c, const char* name, size_t bytes, void** out)
@@ -1063,11 +1064,21 @@ extern "C" int bssm_pf_run(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_resul
     const long long serial = ++g_run_serial[dev];
     const bool alone = (++g_runs_active[dev] == 1);
     if (!alone) g_last_overlap[dev].store(serial);
-    const bool quiet = alone && (g_last_overlap[dev].load() == 0 || serial - g_last_overlap[dev].load() > FZ_QUIET);
+    const bool quiet = alone && (g_last_overlap[dev].load() == 0 || serial - g_last_overlap[dev].load() > FZ_QUIET) && serial > g_fused_hold[dev].load();
     int expected = 0;
     const bool token = quiet && c->opt_fused && c->fz_ok && g_fused_busy[dev].compare_exchange_strong(expected, 1);
+    const long long timeouts0 = c->fz_timeouts;
     int rc = pf_run_impl(c, cfg, res, token);
     if (token) g_fused_busy[dev].store(0);
+    // a time-out means the launch's workgroups were not all resident: the GPU is shared with work this process cannot see (another
+    // process, another library).  Each costs 20 ms before the run is repeated, so the device backs off: 256 runs without a fused attempt
+    // after the first time-out, doubling up to 65 536 while they keep coming
+    if (c->fz_timeouts != timeouts0) {
+        const long long last = g_fused_span[dev].load();
+        const long long span = last > 0 ? (last * 2 > 65536 ? 65536 : last * 2) : 256;
+        g_fused_span[dev].store(span);
+        g_fused_hold[dev].store(serial + span);
+    } else if (token && rc == BSSM_OK) g_fused_span[dev].store(0);
     if (rc == BSSM_RETRY_UNFUSED) rc = pf_run_impl(c, cfg, res, false);      // deterministic: the same draws, the other kernels
     --g_runs_active[dev];
     return rc;
