@@ -768,6 +768,8 @@ def pmmh(pf_wrapper, y, m, init_fn, transition_fn, log_likelihood_fn, log_priors
     priors = [log_priors[k] for k in prior_names]
     use_pilot = num_particles is None or proposal_cov is None
     if seed is None:
+        if kwargs.get("r_stream"):
+            raise ValueError("r_stream needs a seed (the argument of set.seed)")
         seed = int(np.random.default_rng().integers(1, 2 ** 31 - 1))
     # per-chain seeds drawn up-front, so results do not depend on how chains are placed (R/pmmh.R:511)
     seeds = np.random.default_rng(seed).integers(1, 2 ** 31 - 1, size=num_chains)

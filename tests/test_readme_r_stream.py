@@ -94,3 +94,22 @@ def test_r_stream_helpers_of_the_product(replayed):
     assert out["_extras"]["seeds"] == rrng.sample_int_large(rrng.RRandom(1405), 2147483647, 2)
     g = rrng.RRandom(123)
     np.testing.assert_allclose(rrng.rnorm_vec(g, 3), [-0.56047565, -0.23017749, 1.55870831], atol=5e-9)     # set.seed(123); rnorm(3)
+
+
+def test_r_stream_argument_checks():
+    """The verification mode refuses what it cannot replay (no GPU is touched before these checks)."""
+    import bayesssm_amd as B
+    from bayesssm_amd import rrng
+    m = B.models.ar1_sin()
+    pri = {"phi": B.prior_uniform(0.0, 1.0), "sigma_x": B.prior_exponential(1.0), "sigma_y": B.prior_exponential(1.0)}
+    init = [{"phi": 0.4, "sigma_x": 0.4, "sigma_y": 0.4}]
+    y = np.zeros(5)
+    with pytest.raises(ValueError, match="r_stream"):            # the reference's own tuning only: no overrides
+        B.pmmh(B.bootstrap_filter, y, 10, m.init_fn, m.transition_fn, m.log_likelihood_fn, pri, init, 2, num_chains=1, seed=1, r_stream=True,
+               num_particles=64, proposal_cov=np.eye(3) * 0.01)
+    with pytest.raises(ValueError, match="seed"):                # set.seed needs an argument
+        B.pmmh(B.bootstrap_filter, y, 10, m.init_fn, m.transition_fn, m.log_likelihood_fn, pri, init, 2, num_chains=1, seed=None, r_stream=True)
+    with pytest.raises(ValueError, match="mutually exclusive"):
+        B.bootstrap_filter(y, 16, m.init_fn, m.transition_fn, m.log_likelihood_fn, r_seed=1, r_stream=rrng.RRandom(1), phi=0.5, sigma_x=1.0, sigma_y=1.0)
+    with pytest.raises(ValueError, match="hashing case"):
+        rrng.sample_int_large(rrng.RRandom(1), 1000, 2)
