@@ -733,8 +733,9 @@ static int pf_run_impl(bssm_ctx* c, const bssm_pf_config* cfg, bssm_pf_result* r
     const bool relw = c->opt_recompute_lw && !apf && !sir && !c->opt_fuse_step;
     // one launch per observation (fused.hip.h): bootstrap / resample-move filter, scalar Gaussian-observation model, stratified or
     // systematic resampling, at most 512 blocks; the A/B and test switches that select other kernels keep the multi-launch path
-    // (grids of at most FZ_MINB blocks stay on the multi-launch path unless the option is 2: the fused launch's three in-launch hand-offs cost
-    //  ~10 us each whatever N is, the multi-launch kernels shrink with N: measured 52 vs 45 us per observation at N = 2^16 .. 2^18)
+    // (grids of at most FZ_MINB blocks -- one workgroup per CU -- stay on the multi-launch path unless the option is 2: the fused launch's three
+    //  in-launch hand-offs cost the same whatever N is, the multi-launch kernels shrink with N: 46.9 vs 43.2 us per observation at 256 blocks,
+    //  44.1 vs 47.8 at 320: tools/diag_fused_threshold.py)
     const bool fused = allow_fused && c->fz_ok && c->opt_fused && (B > FZ_MINB || c->opt_fused >= 2) && !apf && !sir && B <= FZ_MAXB && !c->sh_nloc && c->opt_renormalize &&
                        !c->opt_fuse_step && c->opt_inkernel_resolve &&
                        (cfg->resample_fn == BSSM_STRATIFIED || cfg->resample_fn == BSSM_SYSTEMATIC);

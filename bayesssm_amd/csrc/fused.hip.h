@@ -31,7 +31,8 @@ typedef unsigned long long fz_u64;
 #define BSSM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr int FZ_MAXB = 2 * NT;        // workers (blocks of EB particles): N <= 2^20
-constexpr int FZ_MINB = 384;           // grids up to this size stay on the multi-launch path by default (option fused = 2 forces the fused one)
+constexpr int FZ_MINB = 256;           // grids up to this size (one workgroup per CU) stay on the multi-launch path by default: measured faster there (43.2 vs 46.9 us at
+                                       // 256 blocks, but 47.8 vs 44.1 at 320: tools/diag_fused_threshold.py); option fused = 2 forces the fused launch at every size
 constexpr int FZ_KREC = 8;             // granules of a block record on the wire
 constexpr int FZ_KSIDE = (int)(sizeof(SideEntry) / 4);     // granules of a side entry
 constexpr int FZ_NREP = 16;           // replicas of a result every worker reads (32 readers a line instead of 512)

@@ -108,7 +108,7 @@ void* bssm_ctx_stream(bssm_ctx* ctx);
 #define BSSM_OPT_DEBUG_STOP 5          /* [0] DEV builds (make DEV=1): stage stamps */
 #define BSSM_OPT_RENORMALIZE 7         /* [1] filters: the resampler's prob = weights / sum(weights) on the already normalised weights (src/resampling.cpp:24,51); 0 folds it away */
 #define BSSM_OPT_RECOMPUTE_LW 8        /* [1] bootstrap filters, Gaussian-observation models: k_step does not store the log-weights, k_weights re-evaluates them */
-#define BSSM_OPT_FUSED 9               /* [1] bootstrap / resample-move filters, scalar Gaussian-observation models, 384 < blocks <= 512 (N ~ 2^19.6 .. 2^20): ONE launch per observation (workgroups keep their particles on chip; block records cross workgroups as tagged granules); 0 = the multi-launch path; 2 = fused at every N <= 2^20 (tests) */
+#define BSSM_OPT_FUSED 9               /* [1] bootstrap / resample-move filters, scalar Gaussian-observation models, 256 < blocks <= 512 (2^19 < N <= 2^20): ONE launch per observation (workgroups keep their particles on chip; block records cross workgroups as tagged granules); 0 = the multi-launch path; 2 = fused at every N <= 2^20 (tests) */
 #define BSSM_OPT_FUSED_PREFETCH 10     /* [0] fused path: the next observation's transition normals are drawn in the time the workgroups wait for the resolver (measured slower: +2 us per observation) */
 #define BSSM_OPT_FUSE_STEP 6           /* [0] SISR bootstrap filters: the next observation's transition + weight inside the expansion kernel */
 int bssm_ctx_set_option(bssm_ctx* ctx, int option, int value);
