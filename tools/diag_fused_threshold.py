@@ -5,7 +5,7 @@ T = 300
 ys = bench.simulate_lg(T)
 m = b.models.linear_gaussian()
 cx = b.Context(0, 1 << 20, 1)
-for N in (1 << 18, 1 << 19, 5 << 17, 6 << 17, 7 << 17, 1 << 20):
+for N in ([int(a) * 2048 for a in sys.argv[1:]] or [1 << 18, 1 << 19, 5 << 17, 6 << 17, 7 << 17, 1 << 20]):
     out = []
     for opt in (2, 0, 2, 0):
         cx.set_option("fused", opt)
